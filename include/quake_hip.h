@@ -1,0 +1,167 @@
+/*
+ * quake_hip.h -- C ABI of libquake_hip.so, the MI355X (gfx950) quantum-kernel engine.
+ *
+ * The reference (qismib/QuaKe) has no FFI: its seam for this path is a Python
+ * duck-type whose arithmetic lives in qiskit / qiskit_machine_learning.  Each
+ * entry point below names the reference call it replaces.  The Python wrapper in
+ * quake_amd/kernels.py binds these with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative qk_status; the message is
+ *     read with qk_last_error() (thread-local);
+ *   - the caller owns every buffer it passes; the library owns qk_circuit handles;
+ *   - "host" entry points take host pointers, allocate device memory themselves,
+ *     and are synchronous; "_dev" entry points take device pointers (hipMalloc'ed
+ *     memory, e.g. a torch tensor's data_ptr()) and a hipStream_t passed as void*,
+ *     and only enqueue work on that stream;
+ *   - statevectors Psi are row-major [N][2^n] interleaved complex128 (re, im);
+ *     Gram matrices are row-major float64;
+ *   - qubit 0 is the least significant bit of the amplitude index.
+ */
+#ifndef QUAKE_HIP_H
+#define QUAKE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum qk_status {
+    QK_OK = 0,
+    QK_ERR_INVALID = -1,     /* bad argument (shape, null pointer, unsupported gate ...) */
+    QK_ERR_HIP = -2,         /* a HIP runtime call failed */
+    QK_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+    QK_ERR_UNSUPPORTED = -4  /* valid request outside what this build implements */
+} qk_status;
+
+/* Gate alphabet reachable on the reference's hot path. */
+typedef enum qk_gate {
+    QK_ID = 0, QK_H, QK_X, QK_SX, QK_RX, QK_RY, QK_RZ, QK_P, QK_CX, QK_CZ, QK_ECR
+} qk_gate;
+
+/* Postfix ops of a gate-angle program, evaluated in IEEE double on the device. */
+typedef enum qk_expr_op {
+    QK_EX_CONST = 0, /* push consts[arg]            */
+    QK_EX_PARAM,     /* push x_row[arg]             */
+    QK_EX_ADD, QK_EX_SUB, QK_EX_MUL, QK_EX_DIV, QK_EX_NEG,
+    QK_EX_ASIN, QK_EX_ACOS, QK_EX_SIN, QK_EX_COS
+} qk_expr_op;
+
+typedef struct qk_op {     /* one gate */
+    int32_t gate;          /* qk_gate */
+    int32_t q0;            /* target (1-qubit gates); first argument (cx: control) */
+    int32_t q1;            /* second argument (cx: target) or -1 */
+    int32_t expr;          /* index of the angle program, or -1 */
+} qk_op;
+
+typedef struct qk_instr {  /* one postfix instruction */
+    int32_t op;            /* qk_expr_op */
+    int32_t arg;
+} qk_instr;
+
+typedef struct qk_circuit qk_circuit; /* opaque */
+
+int qk_version(void);
+int qk_device_count(void);
+/* Copies the calling thread's last error message into buf (NUL-terminated). */
+int qk_last_error(char* buf, size_t len);
+
+/*
+ * Replaces: building a qiskit QuantumCircuit over a ParameterVector
+ * (reference quantum_featuremaps.py:9-387, genetic_v3.py:363-448) plus
+ * QuantumCircuit.assign_parameters: angle program e reads data
+ * column `arg` of QK_EX_PARAM directly, so the sorted-parameter binding is resolved
+ * by the caller when it numbers the columns.
+ *   expr_off has n_expr + 1 entries; program e is prog[expr_off[e] .. expr_off[e+1]).
+ */
+int qk_circuit_create(int n_qubits, int n_params,
+                      const qk_op* ops, int n_ops,
+                      const qk_instr* prog, int n_instr,
+                      const int32_t* expr_off, int n_expr,
+                      const double* consts, int n_consts,
+                      qk_circuit** out);
+void qk_circuit_destroy(qk_circuit* c);
+int qk_circuit_num_qubits(const qk_circuit* c);
+int qk_circuit_num_params(const qk_circuit* c);
+/* Number of HBM passes the simulator plans for this circuit (1 when 2^n amplitudes fit in LDS). */
+int qk_circuit_num_passes(const qk_circuit* c);
+
+/*
+ * Replaces: [Statevector(fmap.assign_parameters(x)).data for x in x_vec]
+ * (qiskit_machine_learning FidelityStatevectorKernel._evaluate; call sites
+ * reference qsvm/train.py:92,152,154, genetic_v3.py:618-619).
+ *   X    : N x n_params float64, row stride ldx (elements)
+ *   psi  : N x 2^n complex128, written
+ */
+int qk_simulate_dev(const qk_circuit* c, const double* X_dev, int64_t N, int64_t ldx,
+                    void* psi_dev, void* stream);
+int qk_simulate(const qk_circuit* c, const double* X, int64_t N, int64_t ldx, void* psi_host);
+
+/*
+ * Replaces: FidelityStatevectorKernel._compute_fidelity over all pairs, i.e.
+ * K[i][j] = |sum_b conj(A[i][b]) * B[j][b]|^2  (SURVEY.md 8a A5).
+ *
+ * One job computes a block K = |A B^H|^2 with A (ma x D) and B (nb x D):
+ *   K [i*ldk  + j] = k_ij                    (always)
+ *   KT[j*ldkt + i] = k_ij                    (if KT != NULL; transposed copy, used to
+ *                                             hand mirror blocks to another GPU)
+ * flags & QK_GRAM_SYMMETRIC: A and B are the same rows (ma == nb); only tiles on or
+ *   above the diagonal are computed, the mirror is written into K itself and the
+ *   diagonal is set to exactly 1.0 (the reference leaves those entries at 1.0).
+ * All jobs of one call run in ONE kernel launch (one tile schedule over all jobs).
+ */
+#define QK_GRAM_SYMMETRIC 1
+typedef struct qk_gram_job {
+    const void* A;    /* device, ma x D complex128 */
+    const void* B;    /* device, nb x D complex128 */
+    double* K;        /* device */
+    double* KT;       /* device or NULL */
+    int64_t ma, nb;
+    int64_t ldk, ldkt;
+    int32_t flags;
+    int32_t reserved;
+} qk_gram_job;
+#define QK_GRAM_MAX_JOBS 16
+int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream);
+/* Convenience over one job: psi_y == NULL means the symmetric train x train block. */
+int qk_gram_dev(const void* psi_x, int64_t N, const void* psi_y, int64_t M, int64_t D,
+                double* K_dev, int64_t ldk, void* stream);
+
+/*
+ * Replaces: kernel.evaluate(x_vec, y_vec=None) of FidelityStatevectorKernel
+ * (reference qsvm/train.py:92,152,154; qsvm_tester.py:684-686; genetic_v3.py:619).
+ * Host pointers; Y == NULL gives the symmetric N x N matrix with unit diagonal.
+ * n_features must equal the circuit's parameter count (else QK_ERR_INVALID, the
+ * wrapper turns it into the reference's ValueError).
+ */
+int qk_evaluate(const qk_circuit* c, const double* X, int64_t N,
+                const double* Y, int64_t M, int n_features, double* K_host);
+
+/*
+ * Replaces: DensityMatrix(...) + partial_trace(dm, all-but-q) for every qubit
+ * (reference genetic_v3.py:795-803).  rdm is N x n x 4 float64:
+ * (rho00, rho11, Re rho01, Im rho01) of qubit q.
+ */
+int qk_rdm1_dev(const void* psi_dev, int64_t N, int n_qubits, double* rdm_dev, void* stream);
+
+/*
+ * Replaces: the pair loop of projected_quantum_kernel (reference genetic_v3.py:793-805):
+ * K[i][j] = exp(-gamma * sum_q ||rho_i^q - rho_j^q||_F)  (un-squared Frobenius norm).
+ * rdm_y == NULL: symmetric N x N with exact unit diagonal.
+ */
+int qk_pqk_dev(const double* rdm_x, int64_t N, const double* rdm_y, int64_t M, int n_qubits,
+               double gamma, double* K_dev, int64_t ldk, void* stream);
+
+/*
+ * Replaces: projected_quantum_kernel(fmap, dataset, gamma) (reference genetic_v3.py:766-806).
+ * Host pointers.  A circuit without parameters yields all ones (reference :789-791).
+ */
+int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t N, int n_features,
+                        double gamma, double* K_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUAKE_HIP_H */

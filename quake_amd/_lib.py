@@ -1,0 +1,127 @@
+"""ctypes binding of libquake_hip.so (C ABI declared in include/quake_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is visible,
+the first call that needs it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "libquake_hip.so"
+
+QK_OK = 0
+QK_ERR_INVALID = -1
+QK_ERR_HIP = -2
+QK_ERR_NO_DEVICE = -3
+QK_ERR_UNSUPPORTED = -4
+QK_GRAM_SYMMETRIC = 1
+QK_GRAM_MAX_JOBS = 16
+
+
+class QkError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libquake_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class qk_gram_job(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("K", C.c_void_p), ("KT", C.c_void_p),
+        ("ma", C.c_int64), ("nb", C.c_int64), ("ldk", C.c_int64), ("ldkt", C.c_int64),
+        ("flags", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# every symbol include/quake_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_I64 = C.c_int64
+SIGNATURES = {
+    "qk_version": (C.c_int, []),
+    "qk_device_count": (C.c_int, []),
+    "qk_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "qk_circuit_create": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
+                                    C.POINTER(_P)]),
+    "qk_circuit_destroy": (None, [_P]),
+    "qk_circuit_num_qubits": (C.c_int, [_P]),
+    "qk_circuit_num_params": (C.c_int, [_P]),
+    "qk_circuit_num_passes": (C.c_int, [_P]),
+    "qk_simulate_dev": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
+    "qk_simulate": (C.c_int, [_P, _P, _I64, _I64, _P]),
+    "qk_gram_jobs_dev": (C.c_int, [C.POINTER(qk_gram_job), C.c_int, _I64, _P]),
+    "qk_gram_dev": (C.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
+    "qk_evaluate": (C.c_int, [_P, _P, _I64, _P, _I64, C.c_int, _P]),
+    "qk_rdm1_dev": (C.c_int, [_P, _I64, C.c_int, _P, _P]),
+    "qk_pqk_dev": (C.c_int, [_P, _I64, _P, _I64, C.c_int, C.c_double, _P, _I64, _P]),
+    "qk_projected_kernel": (C.c_int, [_P, _P, _I64, C.c_int, C.c_double, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m quake_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    load().qk_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != QK_OK:
+        raise QkError(rc, last_error())
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CircuitHandle:
+    """Owns a ``qk_circuit*`` built from a :class:`quake_amd.circuit.CompiledCircuit`."""
+
+    def __init__(self, compiled):
+        lib = load()
+        self.compiled = compiled
+        ops = np.ascontiguousarray(compiled.ops, dtype=np.int32)
+        prog = np.ascontiguousarray(compiled.prog, dtype=np.int32)
+        off = np.ascontiguousarray(compiled.expr_off, dtype=np.int32)
+        consts = np.ascontiguousarray(compiled.consts, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib.qk_circuit_create(
+            compiled.n_qubits, compiled.n_params,
+            ptr(ops), ops.shape[0], ptr(prog), prog.shape[0],
+            ptr(off), off.shape[0] - 1, ptr(consts), consts.shape[0], C.byref(h)))
+        self._h = h
+        self.n_qubits = compiled.n_qubits
+        self.n_params = compiled.n_params
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def num_passes(self) -> int:
+        return load().qk_circuit_num_passes(self._h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.qk_circuit_destroy(h)

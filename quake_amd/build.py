@@ -1,0 +1,60 @@
+"""Build libquake_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+INCLUDE = PKG_DIR.parent / "include"
+LIB_PATH = PKG_DIR / "libquake_hip.so"
+SOURCES = ["qk_api.hip", "qk_circuit.cpp", "qk_sim.hip", "qk_gram.hip", "qk_pqk.hip"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found; libquake_hip.so cannot be built")
+    return exe
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "qk_common.h", INCLUDE / "quake_hip.h"]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> Path:
+    if not force and not needs_build():
+        return LIB_PATH
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-I{INCLUDE}", f"-I{CSRC}",
+             "-Wall", "-Wno-unused-function", *extra_flags]
+    procs = []
+    for s in SOURCES:
+        obj = objdir / (s.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc(), *flags, "-x", "hip", "-c", str(CSRC / s), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, obj, subprocess.Popen(cmd)))
+    objs = []
+    for s, obj, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+        objs.append(str(obj))
+    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    print(LIB_PATH)

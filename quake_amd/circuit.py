@@ -1,0 +1,442 @@
+"""Circuit IR for the quantum-kernel hot path (no qiskit).
+
+The reference builds its feature maps as ``qiskit.QuantumCircuit`` objects over a
+``ParameterVector`` (reference ``src/quake/models/qsvm/quantum_featuremaps.py:4-6``,
+``genetic_v3.py:364-365``).  Qiskit is not part of this build; this module is the
+replacement the builders in :mod:`quake_amd.featuremaps` and :mod:`quake_amd.genetic`
+write into.  It keeps the three behaviours of the Qiskit objects that decide the
+numerical result of the kernel:
+
+* gate angles are symbolic expressions of the free parameters
+  (``2 * (np.pi - x[q]) * (np.pi - x[q + 1])``, ``np.arcsin(2 / np.pi * x[q])`` ...);
+* ``circuit.parameters`` is the *sorted* set of parameters that actually reach a
+  gate -- sorted by (vector name, index) -- and ``assign_parameters(values)`` /
+  ``kernel.evaluate(x_vec)`` bind the k-th value / data column to the k-th element
+  of that sorted list (pinned by golden value P1);
+* qubit 0 is the least significant bit of the amplitude index.
+
+``QuantumCircuit.compile()`` lowers a circuit to the flat program the C-ABI library
+consumes (``include/quake_hip.h``): an op table plus one small postfix program per
+gate angle, evaluated on the device from the raw feature row.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+Number = Union[int, float]
+
+# --------------------------------------------------------------------------- #
+# op codes shared with include/quake_hip.h (enum qk_gate / enum qk_expr_op)
+# --------------------------------------------------------------------------- #
+GATE_ID, GATE_H, GATE_X, GATE_SX, GATE_RX, GATE_RY, GATE_RZ, GATE_P, GATE_CX, GATE_CZ, GATE_ECR = range(11)
+GATE_CODES = {
+    "id": GATE_ID, "h": GATE_H, "x": GATE_X, "sx": GATE_SX, "rx": GATE_RX, "ry": GATE_RY,
+    "rz": GATE_RZ, "p": GATE_P, "cx": GATE_CX, "cz": GATE_CZ, "ecr": GATE_ECR,
+}
+GATE_NAMES = {v: k for k, v in GATE_CODES.items()}
+PARAMETRIC = {"rx", "ry", "rz", "p"}
+TWO_QUBIT = {"cx", "cz", "ecr"}
+
+(EX_CONST, EX_PARAM, EX_ADD, EX_SUB, EX_MUL, EX_DIV, EX_NEG, EX_ASIN, EX_ACOS, EX_SIN, EX_COS) = range(11)
+MAX_EXPR_STACK = 16
+
+
+# --------------------------------------------------------------------------- #
+# symbolic angles
+# --------------------------------------------------------------------------- #
+class ParameterExpression:
+    """A closed-form expression of circuit parameters.
+
+    Supports the arithmetic the reference's builders use on Qiskit
+    ``ParameterExpression`` objects: ``+ - * /`` with numbers and each other, unary
+    minus, and ``np.arcsin`` / ``np.arccos`` / ``np.sin`` / ``np.cos``.
+    """
+
+    __slots__ = ("op", "args")
+    __array_priority__ = 1000
+
+    def __init__(self, op: str, args: tuple):
+        self.op = op
+        self.args = args
+
+    # -- construction helpers ------------------------------------------------
+    @staticmethod
+    def _lift(v) -> "ParameterExpression":
+        if isinstance(v, ParameterExpression):
+            return v
+        if isinstance(v, (int, float, np.integer, np.floating)):
+            return ParameterExpression("const", (float(v),))
+        raise TypeError(f"cannot use {type(v).__name__} in a gate-angle expression")
+
+    def _bin(self, op, other, swap=False):
+        try:
+            o = self._lift(other)
+        except TypeError:
+            return NotImplemented
+        return ParameterExpression(op, (o, self) if swap else (self, o))
+
+    def __add__(self, o): return self._bin("add", o)
+    def __radd__(self, o): return self._bin("add", o, True)
+    def __sub__(self, o): return self._bin("sub", o)
+    def __rsub__(self, o): return self._bin("sub", o, True)
+    def __mul__(self, o): return self._bin("mul", o)
+    def __rmul__(self, o): return self._bin("mul", o, True)
+    def __truediv__(self, o): return self._bin("div", o)
+    def __rtruediv__(self, o): return self._bin("div", o, True)
+    def __neg__(self): return ParameterExpression("neg", (self,))
+    def __pos__(self): return self
+
+    def arcsin(self): return ParameterExpression("asin", (self,))
+    def arccos(self): return ParameterExpression("acos", (self,))
+    def sin(self): return ParameterExpression("sin", (self,))
+    def cos(self): return ParameterExpression("cos", (self,))
+
+    _UFUNCS = {"arcsin": "arcsin", "arccos": "arccos", "sin": "sin", "cos": "cos"}
+    _BIN_UFUNCS = {"add": "add", "subtract": "sub", "multiply": "mul", "true_divide": "div", "divide": "div"}
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method != "__call__" or kwargs:
+            return NotImplemented
+        name = ufunc.__name__
+        if name in self._UFUNCS and len(inputs) == 1:
+            return getattr(self, self._UFUNCS[name])()
+        if name == "negative" and len(inputs) == 1:
+            return -self
+        if name in self._BIN_UFUNCS and len(inputs) == 2:
+            try:
+                a, b = self._lift(inputs[0]), self._lift(inputs[1])
+            except TypeError:
+                return NotImplemented
+            return ParameterExpression(self._BIN_UFUNCS[name], (a, b))
+        return NotImplemented
+
+    # -- inspection ----------------------------------------------------------
+    @property
+    def parameters(self) -> set:
+        out = set()
+        stack = [self]
+        while stack:
+            e = stack.pop()
+            if e.op == "param":
+                out.add(e)
+            elif e.op != "const":
+                stack.extend(e.args)
+        return out
+
+    def evaluate(self, binding: dict) -> float:
+        """Numeric value in IEEE double for ``{Parameter: value}``."""
+        op, a = self.op, self.args
+        if op == "const":
+            return a[0]
+        if op == "param":
+            return float(binding[self])
+        if op == "neg":
+            return -a[0].evaluate(binding)
+        if op == "asin":
+            return math.asin(a[0].evaluate(binding))
+        if op == "acos":
+            return math.acos(a[0].evaluate(binding))
+        if op == "sin":
+            return math.sin(a[0].evaluate(binding))
+        if op == "cos":
+            return math.cos(a[0].evaluate(binding))
+        l, r = a[0].evaluate(binding), a[1].evaluate(binding)
+        if op == "add":
+            return l + r
+        if op == "sub":
+            return l - r
+        if op == "mul":
+            return l * r
+        if op == "div":
+            return l / r
+        raise ValueError(op)
+
+    def postfix(self, column_of: dict, consts: list) -> List[Tuple[int, int]]:
+        """Postfix program ``[(opcode, arg), ...]``; constants are interned in ``consts``."""
+        op, a = self.op, self.args
+        if op == "const":
+            v = a[0]
+            for i, c in enumerate(consts):
+                # bit-exact interning (keeps -0.0 and 0.0 apart)
+                if np.float64(c).tobytes() == np.float64(v).tobytes():
+                    return [(EX_CONST, i)]
+            consts.append(v)
+            return [(EX_CONST, len(consts) - 1)]
+        if op == "param":
+            return [(EX_PARAM, column_of[self])]
+        un = {"neg": EX_NEG, "asin": EX_ASIN, "acos": EX_ACOS, "sin": EX_SIN, "cos": EX_COS}
+        if op in un:
+            return a[0].postfix(column_of, consts) + [(un[op], 0)]
+        bi = {"add": EX_ADD, "sub": EX_SUB, "mul": EX_MUL, "div": EX_DIV}
+        return a[0].postfix(column_of, consts) + a[1].postfix(column_of, consts) + [(bi[op], 0)]
+
+    def stack_depth(self) -> int:
+        if self.op in ("const", "param"):
+            return 1
+        if len(self.args) == 1:
+            return self.args[0].stack_depth()
+        return max(self.args[0].stack_depth(), 1 + self.args[1].stack_depth())
+
+    def __str__(self) -> str:
+        op, a = self.op, self.args
+        if op == "const":
+            return repr(a[0])
+        if op == "param":
+            return self.name  # type: ignore[attr-defined]
+        if len(a) == 1:
+            return f"{'-' if op == 'neg' else op}({a[0]})"
+        sym = {"add": "+", "sub": "-", "mul": "*", "div": "/"}[op]
+        return f"({a[0]} {sym} {a[1]})"
+
+    __repr__ = __str__
+
+
+class Parameter(ParameterExpression):
+    """A free parameter.  Identity (not name) decides equality, as in Qiskit."""
+
+    __slots__ = ("name", "vector", "index")
+
+    def __init__(self, name: str, vector: Optional["ParameterVector"] = None, index: int = 0):
+        super().__init__("param", ())
+        self.name = name
+        self.vector = vector
+        self.index = index
+
+    def sort_key(self):
+        # Qiskit orders circuit.parameters by (vector name, element index) for vector
+        # elements and by name otherwise.
+        return (self.vector.name if self.vector is not None else self.name, self.index)
+
+    def __hash__(self):
+        return id(self)
+
+    def __eq__(self, other):
+        return self is other
+
+    def __ne__(self, other):
+        return self is not other
+
+
+class ParameterVector:
+    """``ParameterVector("x", length)``: ``x[i]`` are :class:`Parameter` objects named ``x[i]``."""
+
+    def __init__(self, name: str, length: int = 0):
+        self.name = name
+        self._params = [Parameter(f"{name}[{i}]", self, i) for i in range(int(length))]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self._params[i]
+        return self._params[int(i)]
+
+    def __len__(self):
+        return len(self._params)
+
+    def __iter__(self):
+        return iter(self._params)
+
+    @property
+    def params(self):
+        return list(self._params)
+
+
+# --------------------------------------------------------------------------- #
+# circuit
+# --------------------------------------------------------------------------- #
+@dataclass
+class Instruction:
+    name: str
+    qubits: Tuple[int, ...]
+    angle: Optional[ParameterExpression] = None
+
+    def __str__(self):
+        q = ",".join(f"q{k}" for k in self.qubits)
+        return f"{self.name}({self.angle}) {q}" if self.angle is not None else f"{self.name} {q}"
+
+
+@dataclass
+class CompiledCircuit:
+    """Flat program handed to ``qk_circuit_create`` (include/quake_hip.h)."""
+
+    n_qubits: int
+    n_params: int
+    ops: np.ndarray        # int32 [n_ops, 4]: gate, q0, q1, expr index (-1 = none)
+    prog: np.ndarray       # int32 [n_instr, 2]: opcode, arg
+    expr_off: np.ndarray   # int32 [n_expr + 1]
+    consts: np.ndarray     # float64 [n_consts]
+
+
+class QuantumCircuit:
+    """The subset of ``qiskit.QuantumCircuit`` the reference's feature maps use."""
+
+    def __init__(self, num_qubits: int):
+        if int(num_qubits) < 1:
+            raise ValueError("a circuit needs at least one qubit")
+        self.num_qubits = int(num_qubits)
+        self.data: List[Instruction] = []
+
+    # -- gates ---------------------------------------------------------------
+    def _q(self, q) -> int:
+        q = int(q)
+        if not 0 <= q < self.num_qubits:
+            raise IndexError(f"qubit index {q} out of range for a {self.num_qubits}-qubit circuit")
+        return q
+
+    def _add1(self, name, q, angle=None):
+        if angle is not None:
+            angle = ParameterExpression._lift(angle)
+        self.data.append(Instruction(name, (self._q(q),), angle))
+        return self
+
+    def _add2(self, name, a, b):
+        a, b = self._q(a), self._q(b)
+        if a == b:
+            raise ValueError(f"duplicate qubit argument {a} for a two-qubit gate")
+        self.data.append(Instruction(name, (a, b)))
+        return self
+
+    def id(self, q): return self._add1("id", q)
+    i = id
+    def h(self, q): return self._add1("h", q)
+    def x(self, q): return self._add1("x", q)
+    def sx(self, q): return self._add1("sx", q)
+    def rx(self, theta, q): return self._add1("rx", q, theta)
+    def ry(self, theta, q): return self._add1("ry", q, theta)
+    def rz(self, theta, q): return self._add1("rz", q, theta)
+    def p(self, lam, q): return self._add1("p", q, lam)
+    def cx(self, c, t): return self._add2("cx", c, t)
+    def cz(self, a, b): return self._add2("cz", a, b)
+    def ecr(self, a, b): return self._add2("ecr", a, b)
+
+    def barrier(self, *qubits):
+        """Barriers do not act on the state; kept so reference-shaped builders read the same."""
+        return self
+
+    def __getattr__(self, name):
+        # `getattr(fmap, gate_name.lower())` is how the genome decoder picks a gate
+        # (reference genetic_v3.py:377).  Controlled rotations appear in some shipped
+        # gate_dicts but are never emitted by the reference (genetic_v3.py:446-447).
+        if name in ("crx", "cry", "crz", "cp"):
+            def unsupported(*a, **k):
+                raise NotImplementedError(
+                    f"two-qubit parametric gate '{name}' is not emitted by the reference decoder "
+                    "and is not part of the supported gate alphabet"
+                )
+            return unsupported
+        raise AttributeError(name)
+
+    # -- parameters ----------------------------------------------------------
+    @property
+    def parameters(self) -> List[Parameter]:
+        seen = set()
+        for ins in self.data:
+            if ins.angle is not None:
+                seen |= ins.angle.parameters
+        return sorted(seen, key=Parameter.sort_key)
+
+    @property
+    def num_parameters(self) -> int:
+        return len(self.parameters)
+
+    @property
+    def qubits(self) -> List[int]:
+        return list(range(self.num_qubits))
+
+    def assign_parameters(self, values) -> "QuantumCircuit":
+        """Bind parameters.  A sequence binds positionally against the sorted
+        ``parameters`` list; a dict binds by parameter (a ``ParameterVector`` key
+        takes a sequence).  Unnamed parameters stay free."""
+        params = self.parameters
+        binding = {}
+        if isinstance(values, dict):
+            for k, v in values.items():
+                if isinstance(k, ParameterVector):
+                    if len(v) != len(k):
+                        raise ValueError("ParameterVector binding has the wrong length")
+                    for p, pv in zip(k, v):
+                        binding[p] = float(pv)
+                else:
+                    binding[k] = float(v)
+        else:
+            values = np.asarray(values, dtype=np.float64).reshape(-1)
+            if len(values) != len(params):
+                raise ValueError(
+                    f"Mismatching number of values and parameters. For partial binding "
+                    f"please pass a dictionary of {{parameter: value}} pairs. "
+                    f"({len(values)} values, {len(params)} parameters)"
+                )
+            binding = {p: float(v) for p, v in zip(params, values)}
+        out = QuantumCircuit(self.num_qubits)
+        for ins in self.data:
+            ang = ins.angle
+            if ang is not None:
+                ang = _substitute(ang, binding)
+            out.data.append(Instruction(ins.name, ins.qubits, ang))
+        return out
+
+    # -- introspection -------------------------------------------------------
+    def count_ops(self) -> dict:
+        out: dict = {}
+        for ins in self.data:
+            out[ins.name] = out.get(ins.name, 0) + 1
+        return out
+
+    def depth(self) -> int:
+        level = [0] * self.num_qubits
+        for ins in self.data:
+            d = 1 + max(level[q] for q in ins.qubits)
+            for q in ins.qubits:
+                level[q] = d
+        return max(level) if level else 0
+
+    def draw(self) -> str:
+        return "\n".join(str(ins) for ins in self.data)
+
+    def __len__(self):
+        return len(self.data)
+
+    # -- lowering ------------------------------------------------------------
+    def compile(self) -> CompiledCircuit:
+        """Lower to the flat program of ``include/quake_hip.h``.
+
+        Data column k feeds the k-th parameter of the sorted ``parameters`` list.
+        """
+        params = self.parameters
+        column_of = {p: k for k, p in enumerate(params)}
+        consts: list = []
+        ops, prog, off = [], [], [0]
+        for ins in self.data:
+            expr = -1
+            if ins.angle is not None:
+                if ins.angle.stack_depth() > MAX_EXPR_STACK:
+                    raise ValueError("gate-angle expression is nested too deeply for the device evaluator")
+                prog.extend(ins.angle.postfix(column_of, consts))
+                off.append(len(prog))
+                expr = len(off) - 2
+            q0 = ins.qubits[0]
+            q1 = ins.qubits[1] if len(ins.qubits) > 1 else -1
+            ops.append((GATE_CODES[ins.name], q0, q1, expr))
+        return CompiledCircuit(
+            n_qubits=self.num_qubits,
+            n_params=len(params),
+            ops=np.asarray(ops, dtype=np.int32).reshape(-1, 4),
+            prog=np.asarray(prog, dtype=np.int32).reshape(-1, 2),
+            expr_off=np.asarray(off, dtype=np.int32),
+            consts=np.asarray(consts, dtype=np.float64),
+        )
+
+
+def _substitute(e: ParameterExpression, binding: dict) -> ParameterExpression:
+    if e.op == "param":
+        return ParameterExpression("const", (binding[e],)) if e in binding else e
+    if e.op == "const":
+        return e
+    args = tuple(_substitute(a, binding) for a in e.args)
+    out = ParameterExpression(e.op, args)
+    if all(a.op == "const" for a in args):
+        return ParameterExpression("const", (out.evaluate({}),))
+    return out

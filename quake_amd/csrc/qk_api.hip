@@ -1,0 +1,204 @@
+// C ABI glue: error reporting, circuit handles and the host-pointer entry points.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "qk_common.h"
+
+namespace qk {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+namespace {
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+int check_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return fail(QK_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    return QK_OK;
+}
+
+// X (N x F, row stride F) -> device; returns pointer or nullptr when F == 0
+int upload_X(const double* X, int64_t N, int F, DevBuf& buf) {
+    if (F == 0 || N == 0) return QK_OK;
+    QK_HIP(buf.alloc((size_t)N * F * sizeof(double)));
+    QK_HIP(hipMemcpy(buf.p, X, (size_t)N * F * sizeof(double), hipMemcpyHostToDevice));
+    return QK_OK;
+}
+}  // namespace
+}  // namespace qk
+
+using namespace qk;
+
+extern "C" int qk_version(void) { return 100; }
+
+extern "C" int qk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int qk_last_error(char* buf, size_t len) {
+    if (!buf || len == 0) return QK_ERR_INVALID;
+    const size_t k = g_last_error.size() < len - 1 ? g_last_error.size() : len - 1;
+    std::memcpy(buf, g_last_error.data(), k);
+    buf[k] = 0;
+    return QK_OK;
+}
+
+extern "C" int qk_circuit_create(int n_qubits, int n_params, const qk_op* ops, int n_ops, const qk_instr* prog,
+                                 int n_instr, const int32_t* expr_off, int n_expr, const double* consts,
+                                 int n_consts, qk_circuit** out) {
+    if (!out) return fail(QK_ERR_INVALID, "qk_circuit_create: out is null");
+    *out = nullptr;
+    if (n_qubits < 1 || n_qubits > 26) return fail(QK_ERR_INVALID, "qk_circuit_create: n_qubits must be in 1..26");
+    if (n_params < 0 || n_ops < 0 || n_instr < 0 || n_expr < 0 || n_consts < 0)
+        return fail(QK_ERR_INVALID, "qk_circuit_create: negative count");
+    if ((n_ops && !ops) || (n_instr && !prog) || (n_expr && !expr_off) || (n_consts && !consts))
+        return fail(QK_ERR_INVALID, "qk_circuit_create: null table");
+    // validate the angle programs once, so the device evaluator needs no checks
+    for (int e = 0; e < n_expr; ++e) {
+        const int s = expr_off[e], t = expr_off[e + 1];
+        if (s < 0 || t < s || t > n_instr) return fail(QK_ERR_INVALID, "qk_circuit_create: bad expr_off");
+        int depth = 0;
+        for (int k = s; k < t; ++k) {
+            const qk_instr& in = prog[k];
+            switch (in.op) {
+                case QK_EX_CONST:
+                    if (in.arg < 0 || in.arg >= n_consts) return fail(QK_ERR_INVALID, "angle program: constant index out of range");
+                    ++depth;
+                    break;
+                case QK_EX_PARAM:
+                    if (in.arg < 0 || in.arg >= n_params) return fail(QK_ERR_INVALID, "angle program: parameter column out of range");
+                    ++depth;
+                    break;
+                case QK_EX_ADD: case QK_EX_SUB: case QK_EX_MUL: case QK_EX_DIV:
+                    if (depth < 2) return fail(QK_ERR_INVALID, "angle program: stack underflow");
+                    --depth;
+                    break;
+                case QK_EX_NEG: case QK_EX_ASIN: case QK_EX_ACOS: case QK_EX_SIN: case QK_EX_COS:
+                    if (depth < 1) return fail(QK_ERR_INVALID, "angle program: stack underflow");
+                    break;
+                default:
+                    return fail(QK_ERR_INVALID, "angle program: unknown opcode");
+            }
+            if (depth > 16) return fail(QK_ERR_INVALID, "angle program: deeper than 16 stack slots");
+        }
+        if (depth != 1) return fail(QK_ERR_INVALID, "angle program: does not leave exactly one value");
+    }
+    qk_circuit* c = new (std::nothrow) qk_circuit();
+    if (!c) return fail(QK_ERR_INVALID, "qk_circuit_create: out of memory");
+    c->n_qubits = n_qubits;
+    c->n_params = n_params;
+    c->prog.assign(prog, prog + n_instr);
+    c->consts.assign(consts, consts + n_consts);
+    const int rc = plan_circuit(*c, ops, n_ops, expr_off, n_expr);
+    if (rc) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return QK_OK;
+}
+
+extern "C" void qk_circuit_destroy(qk_circuit* c) {
+    if (!c) return;
+    free_circuit_device(*c);
+    delete c;
+}
+
+extern "C" int qk_circuit_num_qubits(const qk_circuit* c) { return c ? c->n_qubits : QK_ERR_INVALID; }
+extern "C" int qk_circuit_num_params(const qk_circuit* c) { return c ? c->n_params : QK_ERR_INVALID; }
+extern "C" int qk_circuit_num_passes(const qk_circuit* c) { return c ? (int)c->passes.size() : QK_ERR_INVALID; }
+
+extern "C" int qk_simulate(const qk_circuit* c, const double* X, int64_t N, int64_t ldx, void* psi_host) {
+    if (!c || !psi_host) return fail(QK_ERR_INVALID, "qk_simulate: null pointer");
+    if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate: negative N");
+    if (N == 0) return QK_OK;
+    int rc = check_device();
+    if (rc) return rc;
+    const int F = c->n_params;
+    if (F > 0 && (!X || ldx < F)) return fail(QK_ERR_INVALID, "qk_simulate: X is null or ldx < n_params");
+    DevBuf dX, dPsi;
+    if (F > 0) {
+        QK_HIP(dX.alloc((size_t)N * F * sizeof(double)));
+        QK_HIP(hipMemcpy2D(dX.p, F * sizeof(double), X, ldx * sizeof(double), F * sizeof(double), N,
+                           hipMemcpyHostToDevice));
+    }
+    const size_t bytes = ((size_t)N << c->n_qubits) * 16;
+    QK_HIP(dPsi.alloc(bytes));
+    rc = qk_simulate_dev(c, (const double*)dX.p, N, F, dPsi.p, nullptr);
+    if (rc) return rc;
+    QK_HIP(hipMemcpy(psi_host, dPsi.p, bytes, hipMemcpyDeviceToHost));
+    return QK_OK;
+}
+
+extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,
+                           int n_features, double* K_host) {
+    if (!c || !K_host) return fail(QK_ERR_INVALID, "qk_evaluate: null pointer");
+    if (n_features != c->n_params)
+        return fail(QK_ERR_INVALID, "x_vec and class feature map have incompatible dimensions");
+    if (N < 0 || (Y && M < 0)) return fail(QK_ERR_INVALID, "qk_evaluate: negative row count");
+    if (c->n_params > 0 && ((N && !X))) return fail(QK_ERR_INVALID, "qk_evaluate: X is null");
+    const bool sym = (Y == nullptr);
+    if (sym) M = N;
+    if (N == 0 || M == 0) return QK_OK;
+    int rc = check_device();
+    if (rc) return rc;
+    const int F = c->n_params;
+    const int64_t D = (int64_t)1 << c->n_qubits;
+    DevBuf dX, dY, dPx, dPy, dK;
+    if ((rc = upload_X(X, N, F, dX))) return rc;
+    QK_HIP(dPx.alloc((size_t)N * D * 16));
+    if ((rc = qk_simulate_dev(c, (const double*)dX.p, N, F, dPx.p, nullptr))) return rc;
+    if (!sym) {
+        if ((rc = upload_X(Y, M, F, dY))) return rc;
+        QK_HIP(dPy.alloc((size_t)M * D * 16));
+        if ((rc = qk_simulate_dev(c, (const double*)dY.p, M, F, dPy.p, nullptr))) return rc;
+    }
+    QK_HIP(dK.alloc((size_t)N * M * sizeof(double)));
+    if ((rc = qk_gram_dev(dPx.p, N, sym ? nullptr : dPy.p, M, D, (double*)dK.p, M, nullptr))) return rc;
+    QK_HIP(hipMemcpy(K_host, dK.p, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));
+    return QK_OK;
+}
+
+extern "C" int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t N, int n_features, double gamma,
+                                   double* K_host) {
+    if (!c || !K_host) return fail(QK_ERR_INVALID, "qk_projected_kernel: null pointer");
+    if (N < 0) return fail(QK_ERR_INVALID, "qk_projected_kernel: negative N");
+    if (N == 0) return QK_OK;
+    if (c->n_params == 0) {  // reference genetic_v3.py:789-791
+        for (int64_t k = 0; k < N * N; ++k) K_host[k] = 1.0;
+        return QK_OK;
+    }
+    if (n_features != c->n_params)
+        return fail(QK_ERR_INVALID, "dataset and feature map have incompatible dimensions");
+    if (!X) return fail(QK_ERR_INVALID, "qk_projected_kernel: X is null");
+    int rc = check_device();
+    if (rc) return rc;
+    const int F = c->n_params, n = c->n_qubits;
+    const int64_t D = (int64_t)1 << n;
+    DevBuf dX, dPsi, dR, dK;
+    if ((rc = upload_X(X, N, F, dX))) return rc;
+    QK_HIP(dPsi.alloc((size_t)N * D * 16));
+    if ((rc = qk_simulate_dev(c, (const double*)dX.p, N, F, dPsi.p, nullptr))) return rc;
+    QK_HIP(dR.alloc((size_t)N * n * 4 * sizeof(double)));
+    if ((rc = qk_rdm1_dev(dPsi.p, N, n, (double*)dR.p, nullptr))) return rc;
+    QK_HIP(dK.alloc((size_t)N * N * sizeof(double)));
+    if ((rc = qk_pqk_dev((const double*)dR.p, N, nullptr, N, n, gamma, (double*)dK.p, N, nullptr))) return rc;
+    QK_HIP(hipMemcpy(K_host, dK.p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost));
+    return QK_OK;
+}

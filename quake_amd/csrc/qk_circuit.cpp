@@ -1,0 +1,238 @@
+// Host-side circuit planner: gate list -> passes of LDS-resident stages.
+//
+// What it does, in order:
+//   1. drops identity gates and rewrites  cx(a,b) p(l,b) cx(a,b)  as one diagonal
+//      term "phase l where bit a != bit b" (the ZZ-feature-map entangler,
+//      reference quantum_featuremaps.py:75-78) -- same multiplications, no swaps;
+//   2. merges runs of diagonal gates (p, rz, cz, the term above) into one DIAG stage,
+//      letting diagonal gates sink past later non-diagonal gates they commute with;
+//   3. splits the stage list into passes whose non-diagonal gates only touch
+//      "local" qubits (<= 13, the part of the state one workgroup keeps in LDS).
+#include <algorithm>
+#include <cstring>
+
+#include "qk_common.h"
+
+namespace qk {
+namespace {
+
+struct Item {
+    bool diag;
+    int32_t kind;   // diag: TermKind ; non-diag: StageKind (ST_U1 / ST_CX / ST_ECR)
+    int32_t gate;   // qk_gate for ST_U1
+    int32_t q0, q1;
+    int32_t expr;   // global expr index or -1
+};
+
+struct Proto {      // a stage before virtual-bit translation
+    bool diag;
+    std::vector<Item> terms;  // diag
+    Item nd;                  // non-diag
+};
+
+bool touches(const Item& t, int q) { return t.q0 == q || (t.q1 >= 0 && t.q1 == q); }
+
+}  // namespace
+
+int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr_off, int n_expr) {
+    const int n = c.n_qubits;
+    auto bad_q = [&](int q) { return q < 0 || q >= n; };
+
+    // ---- 1. classify + peephole ------------------------------------------
+    std::vector<Item> items;
+    for (int i = 0; i < n_ops; ++i) {
+        const qk_op& o = ops[i];
+        const bool two = (o.gate == QK_CX || o.gate == QK_CZ || o.gate == QK_ECR);
+        const bool par = (o.gate == QK_RX || o.gate == QK_RY || o.gate == QK_RZ || o.gate == QK_P);
+        if (o.gate < QK_ID || o.gate > QK_ECR) return fail(QK_ERR_INVALID, "unknown gate code in op table");
+        if (bad_q(o.q0) || (two && (bad_q(o.q1) || o.q1 == o.q0)))
+            return fail(QK_ERR_INVALID, "gate qubit index out of range");
+        if (par && (o.expr < 0 || o.expr >= n_expr))
+            return fail(QK_ERR_INVALID, "parametric gate without a valid angle program");
+        if (o.gate == QK_ID) continue;
+        if (o.gate == QK_CX && i + 2 < n_ops) {
+            const qk_op& p = ops[i + 1];
+            const qk_op& x2 = ops[i + 2];
+            if (p.gate == QK_P && p.q0 == o.q1 && p.expr >= 0 && p.expr < n_expr && x2.gate == QK_CX &&
+                x2.q0 == o.q0 && x2.q1 == o.q1) {
+                items.push_back({true, TM_ZZP, 0, o.q0, o.q1, p.expr});
+                i += 2;
+                continue;
+            }
+        }
+        switch (o.gate) {
+            case QK_H: case QK_X: case QK_SX: case QK_RX: case QK_RY:
+                items.push_back({false, ST_U1, o.gate, o.q0, -1, par ? o.expr : -1});
+                break;
+            case QK_RZ: items.push_back({true, TM_RZ, 0, o.q0, -1, o.expr}); break;
+            case QK_P: items.push_back({true, TM_P, 0, o.q0, -1, o.expr}); break;
+            case QK_CZ: items.push_back({true, TM_CZ, 0, o.q0, o.q1, -1}); break;
+            case QK_CX: items.push_back({false, ST_CX, o.gate, o.q0, o.q1, -1}); break;
+            case QK_ECR: items.push_back({false, ST_ECR, o.gate, o.q0, o.q1, -1}); break;
+            default: break;
+        }
+    }
+    c.n_gates = (int)items.size();
+
+    // ---- 2. merge diagonal runs, sinking them past commuting gates ---------
+    std::vector<Proto> seq;
+    std::vector<Item> pending;
+    auto flush = [&]() {
+        if (pending.empty()) return;
+        Proto p;
+        p.diag = true;
+        p.terms.swap(pending);
+        p.nd = Item{};
+        seq.push_back(std::move(p));
+    };
+    for (const Item& it : items) {
+        if (it.diag) {
+            pending.push_back(it);
+            continue;
+        }
+        // qubits on which this gate is NOT diagonal (a cx is diagonal on its control)
+        int nq[2] = {it.kind == ST_CX ? it.q1 : it.q0, it.kind == ST_ECR ? it.q1 : -1};
+        bool blocked = false;
+        for (const Item& t : pending)
+            for (int q : nq)
+                if (q >= 0 && touches(t, q)) blocked = true;
+        if (blocked) flush();
+        Proto p;
+        p.diag = false;
+        p.nd = it;
+        seq.push_back(std::move(p));
+    }
+    flush();
+
+    // ---- 3. passes --------------------------------------------------------
+    const int Lmax = std::min(n, kMaxLocalQubits);
+    const int n_fixed = (n > Lmax) ? std::min(4, n) : 0;  // low qubits kept local: 256-B runs in HBM
+    struct Draft { std::vector<int> S; std::vector<int> stage_ids; int n_expr = 0, n_mat = 0; };
+    std::vector<Draft> drafts;
+    auto new_draft = [&]() {
+        Draft d;
+        if (n <= Lmax) {
+            for (int q = 0; q < n; ++q) d.S.push_back(q);
+        } else {
+            for (int q = 0; q < n_fixed; ++q) d.S.push_back(q);
+        }
+        drafts.push_back(d);
+    };
+    new_draft();
+    for (int s = 0; s < (int)seq.size(); ++s) {
+        const Proto& p = seq[s];
+        std::vector<int> need;
+        int add_expr = 0, add_mat = 0;
+        if (p.diag) {
+            for (const Item& t : p.terms) add_expr += (t.expr >= 0);
+        } else {
+            if (p.nd.kind == ST_U1) { need = {p.nd.q0}; add_mat = 1; add_expr = (p.nd.expr >= 0); }
+            if (p.nd.kind == ST_CX) need = {p.nd.q1};
+            if (p.nd.kind == ST_ECR) need = {p.nd.q0, p.nd.q1};
+        }
+        if (add_expr > kMaxExprPerPass)
+            return fail(QK_ERR_UNSUPPORTED, "too many parametric diagonal gates in one run");
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            Draft& d = drafts.back();
+            std::vector<int> S2 = d.S;
+            for (int q : need)
+                if (std::find(S2.begin(), S2.end(), q) == S2.end()) S2.push_back(q);
+            const bool fits = (int)S2.size() <= Lmax && d.n_expr + add_expr <= kMaxExprPerPass &&
+                              d.n_mat + add_mat <= kMaxMatPerPass;
+            if (fits) {
+                d.S = S2;
+                d.stage_ids.push_back(s);
+                d.n_expr += add_expr;
+                d.n_mat += add_mat;
+                break;
+            }
+            if (attempt == 1) return fail(QK_ERR_UNSUPPORTED, "cannot place gate in a simulator pass");
+            new_draft();
+        }
+    }
+
+    c.passes.clear();
+    c.stages.clear();
+    c.terms.clear();
+    c.exprs.clear();
+    c.mats.clear();
+    for (size_t pi = 0; pi < drafts.size(); ++pi) {
+        Draft& d = drafts[pi];
+        // fill the local set with the lowest unused qubits
+        for (int q = 0; q < n && (int)d.S.size() < Lmax; ++q)
+            if (std::find(d.S.begin(), d.S.end(), q) == d.S.end()) d.S.push_back(q);
+        std::sort(d.S.begin(), d.S.end());
+        Pass ps;
+        ps.L = Lmax;
+        ps.first = (pi == 0);
+        ps.lgT = ps.L >= 11 ? 10 : std::max(6, ps.L - 1);
+        ps.phys = d.S;
+        for (int q = 0; q < n; ++q)
+            if (std::find(d.S.begin(), d.S.end(), q) == d.S.end()) ps.phys.push_back(q);
+        std::vector<int> virt(n);
+        for (int v = 0; v < n; ++v) virt[ps.phys[v]] = v;
+        // deposit runs (virtual -> physical), maximal runs with constant shift
+        ps.nruns = 0;
+        for (int v = 0; v < n;) {
+            int sh = ps.phys[v] - v, v2 = v;
+            uint32_t mask = 0;
+            while (v2 < n && ps.phys[v2] - v2 == sh) mask |= (1u << v2), ++v2;
+            if (ps.nruns >= kMaxRuns) return fail(QK_ERR_UNSUPPORTED, "local qubit set too fragmented");
+            ps.run_mask[ps.nruns] = mask;
+            ps.run_shift[ps.nruns] = sh;  // negative for chunk qubits that sit below local ones
+            ++ps.nruns;
+            v = v2;
+        }
+        ps.stage_off = (int)c.stages.size();
+        ps.expr_off = (int)c.exprs.size();
+        ps.mat_off = (int)c.mats.size();
+        const int lgT_eff = std::min(ps.lgT, ps.L);
+        auto add_expr = [&](int e, double scale) -> int {
+            c.exprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale});
+            return (int)c.exprs.size() - 1 - ps.expr_off;
+        };
+        for (int s : d.stage_ids) {
+            const Proto& p = seq[s];
+            DevStage st{};
+            if (p.diag) {
+                st.kind = ST_DIAG;
+                st.t0 = (int)c.terms.size();
+                std::vector<DevTerm> A, B;
+                for (const Item& t : p.terms) {
+                    DevTerm dt{};
+                    dt.type = t.kind;
+                    dt.va = virt[t.q0];
+                    dt.vb = t.q1 >= 0 ? virt[t.q1] : 0;
+                    dt.cs = t.expr >= 0 ? add_expr(t.expr, t.kind == TM_RZ ? 0.5 : 1.0) : -1;
+                    auto thread_const = [&](int v) { return v < lgT_eff || v >= ps.L; };
+                    const bool isA = thread_const(dt.va) && (t.q1 < 0 || thread_const(dt.vb));
+                    (isA ? A : B).push_back(dt);
+                }
+                st.nA = (int)A.size();
+                st.nB = (int)B.size();
+                c.terms.insert(c.terms.end(), A.begin(), A.end());
+                c.terms.insert(c.terms.end(), B.begin(), B.end());
+            } else {
+                const Item& g = p.nd;
+                st.kind = g.kind;
+                if (g.kind == ST_U1) {
+                    st.va = virt[g.q0];
+                    DevMat m{g.gate, g.expr >= 0 ? add_expr(g.expr, 0.5) : -1};
+                    c.mats.push_back(m);
+                    st.idx = (int)c.mats.size() - 1 - ps.mat_off;
+                } else {
+                    st.va = virt[g.q0];
+                    st.vb = virt[g.q1];
+                }
+            }
+            c.stages.push_back(st);
+        }
+        ps.n_stage = (int)c.stages.size() - ps.stage_off;
+        ps.n_expr = (int)c.exprs.size() - ps.expr_off;
+        ps.n_mat = (int)c.mats.size() - ps.mat_off;
+        c.passes.push_back(ps);
+    }
+    return QK_OK;
+}
+
+}  // namespace qk

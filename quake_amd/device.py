@@ -1,0 +1,119 @@
+"""Device-resident entry points: torch tensors in HBM in, torch tensors out.
+
+torch is plumbing here (device memory, the current HIP stream, torch.distributed);
+every kernel is launched through the ``*_dev`` functions of libquake_hip.so on
+torch's current stream.  Used by ``bench.py`` and :mod:`quake_amd.sharded`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .circuit import QuantumCircuit
+
+
+def _stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dp(t: Optional[torch.Tensor]) -> Optional[C.c_void_p]:
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise ValueError("device entry points need tensors in GPU memory")
+
+
+class DeviceCircuit:
+    """A feature map compiled once and kept as a ``qk_circuit`` handle."""
+
+    def __init__(self, feature_map: QuantumCircuit):
+        self.feature_map = feature_map
+        self.compiled = feature_map.compile()
+        self.handle = _lib.CircuitHandle(self.compiled)
+        self.n_qubits = self.compiled.n_qubits
+        self.n_params = self.compiled.n_params
+        self.dim = 1 << self.n_qubits
+
+    def simulate(self, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """X float64 [N, n_params] (row stride free) -> Psi complex128 [N, 2^n]."""
+        _require_gpu(X, out)
+        if X.dtype != torch.float64 or X.dim() != 2 or X.stride(1) != 1:
+            raise ValueError("X must be a float64 [N, F] tensor with unit column stride")
+        if X.shape[1] != self.n_params:
+            raise ValueError(
+                f"x_vec and class feature map have incompatible dimensions.\n"
+                f"x_vec has {X.shape[1]} dimensions, but feature map has {self.n_params}.")
+        N = X.shape[0]
+        if out is None:
+            out = torch.empty((N, self.dim), dtype=torch.complex128, device=X.device)
+        elif out.dtype != torch.complex128 or tuple(out.shape) != (N, self.dim) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous complex128 [N, 2^n] tensor")
+        ldx = X.stride(0) if N > 1 else max(self.n_params, 1)
+        _lib.check(_lib.load().qk_simulate_dev(self.handle.handle, _dp(X), N, ldx, _dp(out), _stream_ptr()))
+        return out
+
+
+def gram_jobs(jobs: Sequence[dict], D: int) -> None:
+    """Run several block jobs in one launch.  Each job: dict(A=, B=, K=, KT=None, symmetric=False);
+    A, B complex128 [rows, D] contiguous; K (and KT) float64 2-D views with unit column stride."""
+    arr = (_lib.qk_gram_job * len(jobs))()
+    for k, j in enumerate(jobs):
+        A, B, K, KT = j["A"], j["B"], j["K"], j.get("KT")
+        _require_gpu(A, B, K, KT)
+        for t in (A, B):
+            if t.dtype != torch.complex128 or t.dim() != 2 or t.shape[1] != D or not t.is_contiguous():
+                raise ValueError("A and B must be contiguous complex128 [rows, D]")
+        if K.dtype != torch.float64 or K.stride(1) != 1 or tuple(K.shape) != (A.shape[0], B.shape[0]):
+            raise ValueError("K must be float64 [rows(A), rows(B)] with unit column stride")
+        if KT is not None and (KT.dtype != torch.float64 or KT.stride(1) != 1
+                               or tuple(KT.shape) != (B.shape[0], A.shape[0])):
+            raise ValueError("KT must be float64 [rows(B), rows(A)] with unit column stride")
+        arr[k].A, arr[k].B = A.data_ptr(), B.data_ptr()
+        arr[k].K = K.data_ptr()
+        arr[k].KT = KT.data_ptr() if KT is not None else None
+        arr[k].ma, arr[k].nb = A.shape[0], B.shape[0]
+        arr[k].ldk = K.stride(0) if K.shape[0] > 1 else max(K.shape[1], 1)
+        arr[k].ldkt = (KT.stride(0) if KT.shape[0] > 1 else max(KT.shape[1], 1)) if KT is not None else 0
+        arr[k].flags = _lib.QK_GRAM_SYMMETRIC if j.get("symmetric") else 0
+    _lib.check(_lib.load().qk_gram_jobs_dev(arr, len(jobs), D, _stream_ptr()))
+
+
+def gram(psi_x: torch.Tensor, psi_y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K = |Psi_x Psi_y^H|^2; ``psi_y is None`` -> symmetric block with exact unit diagonal."""
+    _require_gpu(psi_x, psi_y, out)
+    N, D = psi_x.shape
+    M = N if psi_y is None else psi_y.shape[0]
+    if out is None:
+        out = torch.empty((N, M), dtype=torch.float64, device=psi_x.device)
+    gram_jobs([dict(A=psi_x, B=psi_x if psi_y is None else psi_y, K=out, symmetric=psi_y is None)], D)
+    return out
+
+
+def rdm1(psi: torch.Tensor, n_qubits: int) -> torch.Tensor:
+    """Per-qubit reduced density matrices, float64 [N, n, 4] = (rho00, rho11, Re rho01, Im rho01)."""
+    _require_gpu(psi)
+    if psi.dtype != torch.complex128 or not psi.is_contiguous() or psi.shape[1] != (1 << n_qubits):
+        raise ValueError("psi must be contiguous complex128 [N, 2^n]")
+    out = torch.empty((psi.shape[0], n_qubits, 4), dtype=torch.float64, device=psi.device)
+    _lib.check(_lib.load().qk_rdm1_dev(_dp(psi), psi.shape[0], n_qubits, _dp(out), _stream_ptr()))
+    return out
+
+
+def pqk(rdm_x: torch.Tensor, rdm_y: Optional[torch.Tensor], gamma: float,
+        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Projected kernel block from RDM tables; ``rdm_y is None`` -> symmetric with unit diagonal."""
+    _require_gpu(rdm_x, rdm_y, out)
+    N, n, _ = rdm_x.shape
+    M = N if rdm_y is None else rdm_y.shape[0]
+    if out is None:
+        out = torch.empty((N, M), dtype=torch.float64, device=rdm_x.device)
+    ldk = out.stride(0) if N > 1 else max(M, 1)
+    _lib.check(_lib.load().qk_pqk_dev(_dp(rdm_x.contiguous()), N, _dp(rdm_y.contiguous()) if rdm_y is not None else None,
+                                      M, n, float(gamma), _dp(out), ldk, _stream_ptr()))
+    return out

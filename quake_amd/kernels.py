@@ -1,0 +1,210 @@
+"""Quantum-kernel objects with the reference's API, computed by hand-written HIP.
+
+* :class:`HipFidelityKernel` stands where the reference constructs
+  ``qiskit_machine_learning.kernels.FidelityStatevectorKernel(feature_map=fmap)``
+  (reference ``qsvm_tester.py:412``, ``genetic_v3.py:618``) and is consumed through
+  ``kernel.evaluate(x_vec, y_vec=None)`` (``qsvm/train.py:92,152,154``).
+* :func:`make_kernels` keeps the signature of reference ``qsvm_tester.py:382-413``.
+* :func:`projected_quantum_kernel` keeps the signature of reference
+  ``genetic_v3.py:766-806``.
+
+All arithmetic (angle evaluation, statevector simulation, the N x M fidelity
+contraction, reduced density matrices) runs on the GPU through
+``libquake_hip.so``; there is no CPU path in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .circuit import Parameter, QuantumCircuit
+
+logger = logging.getLogger("quake_amd.kernels")
+
+# Above this many rows the optional PSD projection (an O(N^3) dense eigendecomposition
+# on the host in the reference) is skipped with a warning.
+PSD_MAX_ROWS = 4096
+
+
+def _as_2d(a, name: str) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype.kind not in "fiu":
+        raise ValueError(f"{name} must be numeric")
+    a = np.ascontiguousarray(a, dtype=np.float64)  # float32 widens exactly
+    if a.ndim > 2:
+        raise ValueError(f"{name} must be a 1D or 2D array")
+    if a.ndim == 1:
+        a = a.reshape(1, -1)   # one sample, as qiskit_machine_learning's _validate_input
+    if a.ndim == 0:
+        a = a.reshape(1, 1)
+    return a
+
+
+class HipFidelityKernel:
+    """``K[i, j] = |<psi(x_i)|psi(y_j)>|^2`` for a parameterised feature map.
+
+    Parameters mirror ``FidelityStatevectorKernel``:
+
+    feature_map:  a :class:`quake_amd.circuit.QuantumCircuit`.  Data column k binds
+                  the k-th element of ``feature_map.parameters`` (sorted order).
+    enforce_psd:  the reference default projects the symmetric matrix onto the PSD
+                  cone with a dense ``eig`` on the host.  K is PSD by construction
+                  up to round-off (entries move by ~1e-15), the projection is
+                  O(N^3), so it is off by default here and, when requested, only
+                  applied up to ``PSD_MAX_ROWS`` rows.
+    training_parameters / parameter_values: bind a subset of the circuit's
+                  parameters (the ``align=True`` theta prefix) to fixed values, the
+                  role ``TrainableFidelityQuantumKernel.assign_training_parameters``
+                  plays in the reference (qsvm_tester.py:404-410).
+    """
+
+    def __init__(self, feature_map: QuantumCircuit, *, enforce_psd: bool = False,
+                 training_parameters: Optional[Sequence[Parameter]] = None,
+                 parameter_values: Optional[Sequence[float]] = None,
+                 shots=None, cache_size=None, auto_clear_cache: bool = True):
+        if shots is not None:
+            raise NotImplementedError("finite-shot fidelity estimation is not implemented")
+        self._feature_map = feature_map
+        self._training_parameters = list(training_parameters) if training_parameters is not None else []
+        self._enforce_psd = bool(enforce_psd)
+        self._handle = None
+        self._bound = None
+        self.parameter_values = None
+        if self._training_parameters:
+            if parameter_values is None:
+                parameter_values = np.zeros(len(self._training_parameters))
+            self.assign_training_parameters(parameter_values)
+        else:
+            self._rebuild()
+
+    # -- reference-visible attributes ------------------------------------------
+    @property
+    def feature_map(self) -> QuantumCircuit:
+        return self._feature_map
+
+    @property
+    def training_parameters(self):
+        return list(self._training_parameters)
+
+    # old-API alias read by the reference at qsvm_tester.py:324,758
+    user_parameters = training_parameters
+
+    @property
+    def num_features(self) -> int:
+        return self._bound.num_parameters
+
+    @property
+    def enforce_psd(self) -> bool:
+        return self._enforce_psd
+
+    def assign_training_parameters(self, values) -> None:
+        values = np.asarray(values, dtype=np.float64).reshape(-1)
+        if len(values) != len(self._training_parameters):
+            raise ValueError("wrong number of training-parameter values")
+        self.parameter_values = values
+        self._rebuild()
+
+    def _rebuild(self) -> None:
+        fm = self._feature_map
+        if self._training_parameters:
+            fm = fm.assign_parameters(dict(zip(self._training_parameters, self.parameter_values)))
+        self._bound = fm
+        self._compiled = fm.compile()
+        self._handle = None  # created on first use: needs the shared library
+
+    def _circuit(self) -> _lib.CircuitHandle:
+        if self._handle is None:
+            self._handle = _lib.CircuitHandle(self._compiled)
+        return self._handle
+
+    # -- the hot path -------------------------------------------------------------
+    def _validate(self, x_vec, y_vec):
+        x = _as_2d(x_vec, "x_vec")
+        nf = self._compiled.n_params
+        if x.shape[1] != nf:
+            raise ValueError(
+                f"x_vec and class feature map have incompatible dimensions.\n"
+                f"x_vec has {x.shape[1]} dimensions, but feature map has {nf}.")
+        y = None
+        if y_vec is not None:
+            y = _as_2d(y_vec, "y_vec")
+            if y.shape[1] != nf:
+                raise ValueError(
+                    f"y_vec and class feature map have incompatible dimensions.\n"
+                    f"y_vec has {y.shape[1]} dimensions, but feature map has {nf}.")
+        return x, y
+
+    def evaluate(self, x_vec, y_vec=None) -> np.ndarray:
+        """Gram matrix, ``float64 [len(x_vec), len(y_vec or x_vec)]``, C-contiguous.
+
+        ``y_vec is None`` gives the symmetric matrix with an exact unit diagonal."""
+        x, y = self._validate(x_vec, y_vec)
+        lib = _lib.load()
+        circ = self._circuit()
+        n, m = x.shape[0], (x.shape[0] if y is None else y.shape[0])
+        K = np.empty((n, m), dtype=np.float64)
+        _lib.check(lib.qk_evaluate(
+            circ.handle, _lib.ptr(x), n,
+            _lib.ptr(y) if y is not None else None, m, x.shape[1], _lib.ptr(K)))
+        if y is None and self._enforce_psd:
+            K = self._make_psd(K)
+        return K
+
+    def statevectors(self, x_vec) -> np.ndarray:
+        """``complex128 [N, 2^n]`` statevectors (``Statevector(fmap.assign_parameters(x)).data``)."""
+        x, _ = self._validate(x_vec, None)
+        lib = _lib.load()
+        circ = self._circuit()
+        psi = np.empty((x.shape[0], 1 << circ.n_qubits), dtype=np.complex128)
+        _lib.check(lib.qk_simulate(circ.handle, _lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(psi)))
+        return psi
+
+    @staticmethod
+    def _make_psd(K: np.ndarray) -> np.ndarray:
+        if K.shape[0] > PSD_MAX_ROWS:
+            logger.warning("enforce_psd skipped: %d rows > %d (K is PSD up to round-off)", K.shape[0], PSD_MAX_ROWS)
+            return K
+        w, v = np.linalg.eig(K)
+        return np.ascontiguousarray((v @ np.diag(np.maximum(0, w)) @ v.transpose()).real)
+
+
+def make_kernels(maps: List[QuantumCircuit], backend=None) -> List[HipFidelityKernel]:
+    """Quantum kernels for a list of feature maps (reference qsvm_tester.py:382-413).
+
+    ``backend`` is accepted and ignored, as in the reference's statevector branch.
+    A map with more parameters than qubits (the ``align=True`` theta prefix) gets its
+    trailing parameters as training parameters, like the reference's
+    ``TrainableFidelityQuantumKernel`` branch (initialised to zero)."""
+    kernels = []
+    for fmap in maps:
+        params = fmap.parameters
+        if len(params) > fmap.num_qubits:
+            theta = params[fmap.num_qubits:]
+            kernels.append(HipFidelityKernel(feature_map=fmap, training_parameters=theta))
+        else:
+            kernels.append(HipFidelityKernel(feature_map=fmap))
+    return kernels
+
+
+def projected_quantum_kernel(fmap: QuantumCircuit, dataset: np.ndarray, gamma: float) -> np.ndarray:
+    """1-RDM projected quantum kernel (reference genetic_v3.py:766-806):
+    ``K_ij = exp(-gamma * sum_q ||rho_i^q - rho_j^q||_F)``, unit diagonal; all ones
+    for a circuit without parameters."""
+    X = _as_2d(dataset, "dataset")
+    N = X.shape[0]
+    if not fmap.parameters:
+        return np.ones((N, N))
+    compiled = fmap.compile()
+    if X.shape[1] != compiled.n_params:
+        raise ValueError(
+            f"Mismatching number of values and parameters: dataset has {X.shape[1]} columns, "
+            f"feature map has {compiled.n_params} parameters.")
+    lib = _lib.load()
+    circ = _lib.CircuitHandle(compiled)
+    K = np.empty((N, N), dtype=np.float64)
+    _lib.check(lib.qk_projected_kernel(circ.handle, _lib.ptr(X), N, X.shape[1], float(gamma), _lib.ptr(K)))
+    return K

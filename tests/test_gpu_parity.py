@@ -1,0 +1,199 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerances (BASELINE.json north_star): |K_hip - K_oracle| <= 1e-10 absolute in FP64.
+The tests hold the kernels to 1e-12 on K and on every statevector amplitude.
+"""
+import numpy as np
+import pytest
+from sklearn.model_selection import cross_val_score
+from sklearn.svm import SVC
+
+from oracle import qk_oracle as O
+from quake_amd import circuit as qc
+from quake_amd import featuremaps as fm
+from quake_amd import genetic
+from quake_amd.kernels import HipFidelityKernel, make_kernels, projected_quantum_kernel
+from tests._helpers import map_pairs, synth_X, two_qubit_pairs
+from tests.test_circuit_ir import GATE_DICT_FULL
+
+pytestmark = pytest.mark.gpu
+TOL_K = 1e-12
+TOL_PSI = 1e-12
+
+
+@pytest.mark.parametrize("n,repeats", [(1, 1), (2, 2), (3, 1), (5, 2), (8, 2), (10, 1)])
+def test_statevectors_all_maps(n, repeats):
+    X = synth_X(37, n, "scaled", 100 + n)
+    for name, (circ, oops, nq) in map_pairs(n, repeats).items():
+        got = HipFidelityKernel(circ).statevectors(X)
+        ref = O.statevectors(oops, nq, X)
+        assert got.shape == ref.shape and got.dtype == np.complex128
+        assert np.abs(got - ref).max() < TOL_PSI, (name, n, repeats)
+
+
+@pytest.mark.parametrize("repeats", [1, 3])
+def test_statevectors_two_qubit_maps(repeats):
+    X = synth_X(20, 2, "scaled", 7)
+    for name, (circ, oops, nq) in two_qubit_pairs(repeats).items():
+        Xn = X[:, :circ.num_parameters]
+        got = HipFidelityKernel(circ).statevectors(Xn)
+        assert np.abs(got - O.statevectors(oops, nq, Xn)).max() < TOL_PSI, name
+
+
+@pytest.mark.parametrize("n,builder,repeats,N", [
+    (12, "zz", 1, 5), (13, "custom1", 1, 3), (14, "zz", 2, 3), (15, "custom1", 1, 2), (16, "zz", 1, 2), (16, "custom1", 2, 2),
+])
+def test_statevectors_large_and_multipass(n, builder, repeats, N):
+    """n > 13 does not fit one workgroup's LDS: the simulator runs several HBM passes."""
+    X = synth_X(N, n, "scaled", 200 + n)
+    circ, oops, _ = map_pairs(n, repeats)[builder]
+    k = HipFidelityKernel(circ)
+    got = k.statevectors(X)
+    if n > 13:
+        assert k._circuit().num_passes >= 2
+    assert np.abs(got - O.statevectors(oops, n, X)).max() < TOL_PSI
+
+
+@pytest.mark.parametrize("N,M", [(1, 1), (5, 3), (130, 57), (257, 129)])
+def test_evaluate_symmetric_and_cross(N, M):
+    n = 6
+    x = qc.ParameterVector("x", n)
+    circ = fm.zz_featuremap(x, n, 2)
+    oops = O.zz_featuremap(n, 2)
+    X, Y = synth_X(N, n, "scaled", 1), synth_X(M, n, "scaled", 2)
+    k = HipFidelityKernel(circ)
+    K = k.evaluate(x_vec=X)
+    Kref = O.evaluate(oops, n, X)
+    assert K.shape == (N, N) and K.dtype == np.float64 and K.flags["C_CONTIGUOUS"]
+    assert np.abs(K - Kref).max() < TOL_K
+    assert np.array_equal(np.diag(K), np.ones(N))          # exact unit diagonal
+    assert np.array_equal(K, K.T)                          # mirrored, bit-symmetric
+    Kc = k.evaluate(x_vec=X, y_vec=Y)
+    assert Kc.shape == (N, M)
+    assert np.abs(Kc - O.evaluate(oops, n, X, Y)).max() < TOL_K
+
+
+def test_golden_pins_on_gpu(pins, data8, data_labels):
+    p = pins["P1"]
+    fmap, xi = genetic.to_quantum(p["genes"], p["gate_dict"], 8, 8, 4, verbose=False)
+    K = HipFidelityKernel(feature_map=fmap).evaluate(x_vec=data8[:, xi])   # float32 input, widened exactly
+    assert abs(K[25, 41] - p["expected"]) < 1e-14
+    p = pins["P2"]
+    fmap, xi = genetic.to_quantum(p["genes"], p["gate_dict"], 8, 8, 4, verbose=False)
+    K = HipFidelityKernel(feature_map=fmap).evaluate(x_vec=data8[:, xi])
+    acc = cross_val_score(SVC(kernel="precomputed", C=1), K, data_labels, cv=5, scoring="accuracy").mean()
+    assert acc == pytest.approx(p["expected_cv_accuracy"], abs=1e-12)
+    oops, oxi = O.to_quantum(p["genes"], p["gate_dict"], 8, 8, 4)
+    Kref = O.evaluate(oops, 4, data8[:, oxi])
+    assert np.abs(K - Kref).max() < TOL_K
+    # identical SVC predictions from the two Gram matrices
+    a = SVC(kernel="precomputed", C=1).fit(K, data_labels).predict(K)
+    b = SVC(kernel="precomputed", C=1).fit(Kref, data_labels).predict(Kref)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("variant,Q", [("v3", 4), ("v5", 10)])
+def test_genome_circuits(variant, Q):
+    """Config 3 in miniature: heterogeneous genomes, every gate of the alphabet."""
+    rng = np.random.default_rng(31)
+    G, F, N = 8, 18, 48
+    cmap = [[q, q + 1] for q in range(Q - 1)] + [[q + 1, q] for q in range(Q - 1)] if variant == "v5" else None
+    phys = list(range(Q))
+    checked = 0
+    for trial in range(6):
+        genes = genetic.initial_population(1, Q, G, GATE_DICT_FULL, F, rng=rng)[0]
+        kw = dict(coupling_map=cmap, variant=variant, physical_qubits=phys)
+        fmap, xi = genetic.to_quantum(genes, GATE_DICT_FULL, F, G, Q, verbose=False, **kw)
+        oops, oxi = O.to_quantum(genes, GATE_DICT_FULL, F, G, Q, **kw)
+        X = synth_X(N, F, "unit", trial)[:, xi]
+        k = HipFidelityKernel(fmap)
+        assert np.abs(k.statevectors(X) - O.statevectors(oops, Q, X)).max() < TOL_PSI
+        assert np.abs(k.evaluate(X) - O.evaluate(oops, Q, X)).max() < TOL_K
+        checked += 1
+    assert checked == 6
+
+
+def test_projected_kernel(pins, data8):
+    n, N = 5, 70
+    x = qc.ParameterVector("x", n)
+    X = synth_X(N, n, "scaled", 9)
+    for circ, oops in ((fm.zz_featuremap(x, n, 1), O.zz_featuremap(n, 1)),
+                       (fm.custom1_featuremap(x, n, 2), O.custom1_featuremap(n, 2))):
+        K = projected_quantum_kernel(circ, X, 1.0)
+        Kref = O.projected_kernel(oops, n, X, 1.0)
+        assert np.abs(K - Kref).max() < TOL_K
+        assert np.array_equal(np.diag(K), np.ones(N)) and np.array_equal(K, K.T)
+    K2 = projected_quantum_kernel(fm.zz_featuremap(x, n, 1), X, 0.37)
+    assert np.abs(K2 - O.projected_kernel(O.zz_featuremap(n, 1), n, X, 0.37)).max() < TOL_K
+    # a genome circuit on the bundled data
+    p = pins["P1"]
+    fmap, xi = genetic.to_quantum(p["genes"], p["gate_dict"], 8, 8, 4, verbose=False)
+    oops, _ = O.to_quantum(p["genes"], p["gate_dict"], 8, 8, 4)
+    assert np.abs(projected_quantum_kernel(fmap, data8[:, xi], 1) - O.projected_kernel(oops, 4, data8[:, xi], 1)).max() < TOL_K
+    # no parameters -> all ones (reference genetic_v3.py:789-791)
+    c = qc.QuantumCircuit(2)
+    c.h(0)
+    assert np.array_equal(projected_quantum_kernel(c, np.zeros((4, 0)), 1.0), np.ones((4, 4)))
+
+
+def test_api_shapes_and_errors():
+    n = 3
+    x = qc.ParameterVector("x", n)
+    k = HipFidelityKernel(fm.z_featuremap(x, n))
+    with pytest.raises(ValueError):
+        k.evaluate(np.zeros((4, n + 1)))
+    with pytest.raises(ValueError):
+        k.evaluate(np.zeros((4, n)), np.zeros((4, n - 1)))
+    one = k.evaluate(np.array([0.1, 0.2, 0.3]))            # 1-D input = one sample
+    assert one.shape == (1, 1) and one[0, 0] == 1.0
+    cross = k.evaluate(np.array([0.1, 0.2, 0.3]), np.array([[0.1, 0.2, 0.3], [0.3, 0.2, 0.1]]))
+    assert cross.shape == (1, 2) and abs(cross[0, 0] - 1.0) < 1e-14
+    # float32 and integer inputs widen exactly
+    Xf = synth_X(9, n, "scaled", 3).astype(np.float32)
+    assert np.array_equal(k.evaluate(Xf), k.evaluate(Xf.astype(np.float64)))
+    # a circuit without parameters: every state identical, K == 1
+    c = qc.QuantumCircuit(2)
+    c.h(0); c.cx(0, 1); c.sx(1)
+    K = HipFidelityKernel(c).evaluate(np.zeros((5, 0)))
+    assert np.abs(K - 1).max() < 1e-14
+    # make_kernels keeps the reference's signature; align=True maps get training parameters
+    ks = make_kernels([fm.zz_featuremap(x, n), fm.zz_featuremap(x, n, align=True)], backend=None)
+    assert ks[0].training_parameters == [] and len(ks[1].training_parameters) == n
+    X = synth_X(6, n, "scaled", 5)
+    assert np.abs(ks[1].evaluate(X) - ks[0].evaluate(X)).max() < 1e-13     # theta = 0: rx(0) = identity
+    ks[1].assign_training_parameters([0.3, -0.2, 0.9])
+    th = np.tile([0.3, -0.2, 0.9], (6, 1))
+    # oracle: rx(theta_q) prefix then the zz map
+    oops = [("rx", (q,), (lambda P, q=q: P[:, n + q]), (n + q,)) for q in range(n)] + O.zz_featuremap(n, 1)
+    ref = O.fidelity_kernel(O.simulate(oops, n, np.hstack([X, th])))
+    assert np.abs(ks[1].evaluate(X) - ref).max() < TOL_K
+
+
+def test_gram_raw_layout_asymmetric():
+    """MFMA operand/result layout check on data that is neither normalised nor symmetric."""
+    import torch
+    from quake_amd import device as dev
+
+    rng = np.random.default_rng(77)
+    for (N, M, D) in [(200, 300, 64), (129, 17, 8), (16, 16, 4), (3, 2, 2), (140, 140, 256)]:
+        A = rng.normal(size=(N, D)) + 1j * rng.normal(size=(N, D))
+        B = rng.normal(size=(M, D)) + 1j * rng.normal(size=(M, D))
+        ref = np.abs(A.conj() @ B.T) ** 2
+        tA, tB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        KT = torch.zeros((M, N), dtype=torch.float64, device="cuda")
+        K = torch.zeros((N, M), dtype=torch.float64, device="cuda")
+        dev.gram_jobs([dict(A=tA, B=tB, K=K, KT=KT)], D)
+        torch.cuda.synchronize()
+        scale = ref.max()
+        assert np.abs(K.cpu().numpy() - ref).max() < 1e-13 * scale, (N, M, D)
+        assert np.array_equal(KT.cpu().numpy(), K.cpu().numpy().T)
+        # strided output view + symmetric job in the same launch
+        big = torch.full((N + 3, N + 5), -1.0, dtype=torch.float64, device="cuda")
+        dev.gram_jobs([dict(A=tA, B=tA, K=big[1:N + 1, 2:N + 2], symmetric=True),
+                       dict(A=tA, B=tB, K=K)], D)
+        torch.cuda.synchronize()
+        S = big.cpu().numpy()
+        refs = np.abs(A.conj() @ A.T) ** 2
+        np.fill_diagonal(refs, 1.0)
+        assert np.abs(S[1:N + 1, 2:N + 2] - refs).max() < 1e-13 * refs.max()
+        assert (S[0] == -1).all() and (S[:, :2] == -1).all() and (S[N + 1:] == -1).all() and (S[:, N + 2:] == -1).all()
