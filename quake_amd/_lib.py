@@ -62,6 +62,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7) and
+    look it up by the unversioned file name, so a process that loads /opt/rocm's copy
+    first (through this library) and imports torch later ends up with two HIP
+    runtimes, and the second finds no GPU.  Loading torch's copy first -- without
+    importing torch -- makes both sides resolve to the same runtime in either order."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    hip = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if hip.exists():
+        C.CDLL(str(hip), mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load the library (once).  Raises if it has not been built."""
     global _lib
@@ -70,6 +92,7 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m quake_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
