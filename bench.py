@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gram-kernel entries/s for the 16-qubit, N=65536 train x train
+fidelity kernel (BASELINE.json metric; configs[4], which fits one MI355X: Psi 64 GiB +
+K 32 GiB of 288 GB).
+
+One step = the whole hot path over one batch of synthetic inputs that already sit in
+HBM: simulate the rank's statevector shard -> (N>1: all-gather Psi over RCCL) ->
+FP64-MFMA Gram of the rank's share -> (N>1: hand mirrored blocks to their owners).
+N GPUs split the SAME N=65536 problem (strong scaling); `value` is delivered entries
+(N^2, both triangles written) per second of max-over-ranks wall time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--qubits Q]
+
+For N>1 launch with torch.distributed.run (one rank per GPU).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=65536, help="N (default: the north-star size)")
+    ap.add_argument("--qubits", type=int, default=16)
+    ap.add_argument("--repeats", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--check", action="store_true", help="spot-check K against the oracle after the run")
+    return ap.parse_args()
+
+
+def cpu_baseline(X_host, n, repeats, rows):
+    """The oracle's C twin (oracle/qk_oracle.c) on one host core: gate-by-gate statevector
+    per sample, then one |vdot|^2 per pair (j >= i, mirrored) -- the algorithm
+    FidelityStatevectorKernel runs, minus its Python overhead and its O(N^3) eig."""
+    from oracle import qk_oracle as O
+    from oracle import qk_oracle_c as OC
+
+    OC.load()
+    ops = O.zz_featuremap(n, repeats)
+    Xs = np.ascontiguousarray(X_host[:rows])
+    t0 = time.perf_counter()
+    psi = OC.simulate(ops, n, Xs)
+    t1 = time.perf_counter()
+    K = OC.fidelity(psi)
+    t2 = time.perf_counter()
+    return {
+        "value": rows * rows / (t2 - t0),
+        "unit": "entries/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {rows} rows of the same X, n={n} zz_featuremap r={repeats}, train x train; "
+                  f"simulate {t1 - t0:.2f}s + pair loop {t2 - t1:.2f}s "
+                  f"(pair loop alone: {rows * rows / (t2 - t1):.3e} entries/s, the large-N limit)",
+        "host": f"{os.cpu_count()} logical CPUs visible; 1 thread used",
+    }, K, Xs
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from quake_amd import device as qdev, featuremaps as fm, sharded
+    from quake_amd.circuit import ParameterVector
+
+    N, n = a.rows, a.qubits
+    D = 1 << n
+    sharded.check_shape(N, world)
+    r0, r1 = sharded.row_range(rank, world, N)
+
+    # synthetic inputs of SURVEY.md 8d (config 5): range produced by rearrange_scale
+    rng = np.random.default_rng(1005)
+    lo, hi = -np.pi / 2 + 1e-5, np.pi / 2 - 1e-5
+    X_host = rng.uniform(lo, hi, size=(N, n))
+    X = torch.from_numpy(X_host[r0:r1].copy()).to(dev)
+
+    circ = qdev.DeviceCircuit(fm.zz_featuremap(ParameterVector("x", n), n, a.repeats))
+    psi = torch.empty((N, D), dtype=torch.complex128, device=dev)
+    K = torch.empty((r1 - r0, N), dtype=torch.float64, device=dev)
+    sg = sharded.ShardedGram(N, D, rank, world)
+    sg.allocate(dev, torch)
+
+    ev = {}
+
+    def timer(tag):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.setdefault(tag, []).append(e)
+
+    def step(timed):
+        t = timer if timed else None
+        if t: t("sim_begin")
+        circ.simulate(X, out=psi[r0:r1])
+        if t: t("sim_end")
+        work = None
+        if world > 1:
+            work = dist.all_gather_into_tensor(psi, psi[r0:r1], async_op=True)
+        sg.compute(psi, K, gather_work=work, timer=t)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    gram_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(ev["gram_begin"], ev["gram_end"])])) if a.steps else 0.0
+    sim_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(ev["sim_begin"], ev["sim_end"])])) if a.steps else 0.0
+    entries_rank = sharded.computed_entries(rank, world, N)
+    flops_rank = 8.0 * D * entries_rank
+    achieved = flops_rank / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "Gram kernel entries/sec (whole node) at 16 qubits, N=65536; % FP64 MFMA peak",
+            "value": N * N * a.steps / dt,
+            "unit": "entries/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / max(a.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n}-qubit zz_featuremap r={a.repeats} fidelity kernel, N={N} train x train "
+                            f"(BASELINE configs[4]), symmetric: N(N+1)/2 entries computed, N^2 delivered",
+                "rows": N, "qubits": n, "parallelism": f"row-block x{world}",
+            },
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "kernel": "qk::gram_kernel", "ms_per_launch_set": gram_ms,
+                "algorithmic_flops": flops_rank,
+                "note": "8*D real flops per computed entry (rank 0's share); per-GPU peak",
+            },
+            "stages_ms": {"simulate": sim_ms, "gram": gram_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            rows = a.cpu_rows or max(32, min(384, int(384 * (65536 / D) ** 0.5)))
+            rows = min(rows, N)
+            base, K_cpu, _ = cpu_baseline(X_host, n, a.repeats, rows)
+            out["cpu_baseline"] = base
+            if a.check:
+                err = float(np.abs(K[:rows, :rows].cpu().numpy() - K_cpu).max())
+                out["check_max_abs_err_vs_oracle"] = err
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+"""Row-block sharding of the train x train Gram matrix over the GPUs of one node.
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI).
+Rank g owns rows ``[g*N/G, (g+1)*N/G)``:
+
+1. it simulates the statevectors of its rows (no exchange);
+2. ONE data exchange replicates the compact statevector matrix: an all-gather of
+   the Psi shards (the only collective on the path);
+3. it computes its share of the symmetric matrix.  Computing the full row block
+   would do every off-diagonal entry twice across the node, so the blocks are dealt
+   out circulantly instead: rank g computes its diagonal block (upper triangle),
+   the blocks ``(g, g+d)`` for ``d = 1 .. ceil(G/2)-1`` and, for even G, half of
+   block ``(g, g+G/2)``.  Every rank gets exactly 1/G of the N(N+1)/2 entries;
+4. the kernel writes each off-diagonal entry twice -- into the rank's own row block
+   and, transposed, into a staging buffer that is sent point-to-point to the rank
+   owning the mirror rows (each ordered pair of ranks exchanges at most one block).
+
+The result on rank g is the complete row block ``K[g*N/G:(g+1)*N/G, :]``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
+
+
+@dataclass(frozen=True)
+class BlockTask:
+    """Compute ``|Psi[a0:a1] Psi[b0:b1]^H|^2`` on this rank.
+
+    ``peer`` is the rank that owns rows b0:b1 (== own rank for the diagonal block);
+    for ``peer != rank`` the transposed block is sent there."""
+    a0: int
+    a1: int
+    b0: int
+    b1: int
+    peer: int
+    symmetric: bool
+
+
+def row_range(rank: int, world: int, N: int) -> Tuple[int, int]:
+    return (N // world) * rank, (N // world) * (rank + 1)
+
+
+def check_shape(N: int, world: int) -> None:
+    if N % world != 0:
+        raise ValueError(f"N={N} must be divisible by the number of GPUs ({world})")
+    if world % 2 == 0 and world > 1 and (N // world) % 2 != 0:
+        raise ValueError("with an even number of GPUs each row block must have an even number of rows")
+
+
+def plan_tasks(rank: int, world: int, N: int) -> List[BlockTask]:
+    """Block tasks of one rank (see module docstring)."""
+    check_shape(N, world)
+    g0, g1 = row_range(rank, world, N)
+    tasks = [BlockTask(g0, g1, g0, g1, rank, True)]
+    for d in range(1, (world + 1) // 2):
+        h = (rank + d) % world
+        h0, h1 = row_range(h, world, N)
+        tasks.append(BlockTask(g0, g1, h0, h1, h, False))
+    if world % 2 == 0 and world > 1:
+        h = (rank + world // 2) % world
+        h0, h1 = row_range(h, world, N)
+        if rank < world // 2:     # first half of my rows against all of the partner's rows
+            tasks.append(BlockTask(g0, (g0 + g1) // 2, h0, h1, h, False))
+        else:                     # all of my rows against the second half of the partner's rows
+            tasks.append(BlockTask(g0, g1, (h0 + h1) // 2, h1, h, False))
+    return tasks
+
+
+def incoming(rank: int, world: int, N: int) -> List[Tuple[int, BlockTask]]:
+    """(sender, the sender's task) for every mirror block this rank receives."""
+    out = []
+    for s in range(world):
+        if s == rank:
+            continue
+        for t in plan_tasks(s, world, N):
+            if t.peer == rank and not t.symmetric:
+                out.append((s, t))
+    return out
+
+
+def computed_entries(rank: int, world: int, N: int) -> int:
+    """Gram entries this rank computes (upper triangle incl. diagonal for its own block)."""
+    n = 0
+    for t in plan_tasks(rank, world, N):
+        r, c = t.a1 - t.a0, t.b1 - t.b0
+        n += r * (r + 1) // 2 if t.symmetric else r * c
+    return n
+
+
+class ShardedGram:
+    """Executes the plan on torch tensors.  ``gram_jobs(jobs, D)`` defaults to the HIP
+    launcher :func:`quake_amd.device.gram_jobs`."""
+
+    def __init__(self, N: int, D: int, rank: int = 0, world: int = 1, group=None,
+                 gram_jobs: Optional[Callable] = None):
+        check_shape(N, world)
+        self.N, self.D, self.rank, self.world, self.group = N, D, rank, world, group
+        if gram_jobs is None:
+            from .device import gram_jobs as hip_gram_jobs
+            gram_jobs = hip_gram_jobs
+        self._gram_jobs = gram_jobs
+        self.tasks = plan_tasks(rank, world, N)
+        self.recv = incoming(rank, world, N)
+        self._stage = None
+
+    def allocate(self, device, torch):
+        """Staging buffers for the transposed blocks (send) and the incoming ones (recv)."""
+        f64 = torch.float64
+        self._stage = {
+            "send": [torch.empty((t.b1 - t.b0, t.a1 - t.a0), dtype=f64, device=device)
+                     for t in self.tasks if not t.symmetric],
+            "recv": [torch.empty((t.b1 - t.b0, t.a1 - t.a0), dtype=f64, device=device)
+                     for _, t in self.recv],
+        }
+
+    def _jobs(self, psi_full, K_block, tasks, sends):
+        g0, _ = row_range(self.rank, self.world, self.N)
+        jobs = []
+        for t in tasks:
+            job = dict(A=psi_full[t.a0:t.a1], B=psi_full[t.b0:t.b1],
+                       K=K_block[t.a0 - g0:t.a1 - g0, t.b0:t.b1], symmetric=t.symmetric)
+            if not t.symmetric:
+                job["KT"] = sends.pop(0)
+            jobs.append(job)
+        return jobs
+
+    def compute(self, psi_full, K_block, gather_work=None, timer=None):
+        """psi_full: complex128 [N, D] (own shard valid; the rest valid once ``gather_work``
+        completes).  K_block: float64 [N/G, N], fully written on return."""
+        import torch
+        import torch.distributed as dist
+
+        if self._stage is None:
+            self.allocate(K_block.device, torch)
+        sends = list(self._stage["send"])
+        diag = [t for t in self.tasks if t.symmetric]
+        rest = [t for t in self.tasks if not t.symmetric]
+        # the diagonal block only needs the local shard: it overlaps the all-gather
+        if timer: timer("gram_begin")
+        self._gram_jobs(self._jobs(psi_full, K_block, diag, sends), self.D)
+        if gather_work is not None:
+            gather_work.wait()
+        if rest:
+            self._gram_jobs(self._jobs(psi_full, K_block, rest, sends), self.D)
+        if timer: timer("gram_end")
+        if self.world == 1:
+            return K_block
+        ops = []
+        for buf, t in zip(self._stage["send"], rest):
+            ops.append(dist.P2POp(dist.isend, buf, t.peer, group=self.group))
+        for buf, (src, _) in zip(self._stage["recv"], self.recv):
+            ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        g0, _ = row_range(self.rank, self.world, self.N)
+        for buf, (_, t) in zip(self._stage["recv"], self.recv):
+            # sender computed rows a0:a1 x my rows b0:b1 and sent the transpose [b, a]
+            K_block[t.b0 - g0:t.b1 - g0, t.a0:t.a1].copy_(buf)
+        return K_block
