@@ -87,63 +87,65 @@ __global__ void __launch_bounds__(GRAM_THREADS, 2) gram_kernel(GramArgs args) {
     // ---- global -> register staging map: lanes 0..7 cover 128 contiguous bytes of a row
     const int ld_k = tid & 7;
     const int ld_r = tid >> 3;  // 0..63 (+64 for the second element)
-    const double2* gA[2];
-    const double2* gB[2];
-    for (int h = 0; h < 2; ++h) {
-        int64_t ra = row0 + ld_r + 64 * h, rb = col0 + ld_r + 64 * h;
-        if (ra >= J.ma) ra = J.ma - 1;  // clamp: values land in rows that are never stored
-        if (rb >= J.nb) rb = J.nb - 1;
-        gA[h] = J.A + ra * D + ld_k;
-        gB[h] = J.B + rb * D + ld_k;
-    }
+    // clamp rows: values of clamped rows land in LDS rows whose results are never stored
+    const int64_t ra0_ = min(row0 + ld_r, J.ma - 1), ra1_ = min(row0 + ld_r + 64, J.ma - 1);
+    const int64_t rb0_ = min(col0 + ld_r, J.nb - 1), rb1_ = min(col0 + ld_r + 64, J.nb - 1);
     const bool k_in_range = ld_k < D;  // D < BK only for circuits under 3 qubits
+    const int ldk_c = k_in_range ? ld_k : 0;
+    const double2* gA0 = J.A + ra0_ * D + ldk_c;
+    const double2* gA1 = J.A + ra1_ * D + ldk_c;
+    const double2* gB0 = J.B + rb0_ * D + ldk_c;
+    const double2* gB1 = J.B + rb1_ * D + ldk_c;
 
     double2* As0 = smem;
     double2* Bs0 = smem + BK * LDA;
     constexpr int BUF = 2 * BK * LDA;
+    const int st_off = ld_k * LDA + ld_r;
 
     v4d accR[4][2], accI[4][2];
+#pragma unroll
     for (int m = 0; m < 4; ++m)
+#pragma unroll
         for (int n = 0; n < 2; ++n) {
             accR[m][n] = (v4d){0, 0, 0, 0};
             accI[m][n] = (v4d){0, 0, 0, 0};
         }
 
     const int64_t ktiles = (D + BK - 1) / BK;
-    double2 ra[2], rb[2];
     const double2 zero2 = make_double2(0.0, 0.0);
     // prologue: tile 0 -> LDS buffer 0
-    for (int h = 0; h < 2; ++h) {
-        ra[h] = k_in_range ? gA[h][0] : zero2;
-        rb[h] = k_in_range ? gB[h][0] : zero2;
-    }
-    for (int h = 0; h < 2; ++h) {
-        As0[ld_k * LDA + ld_r + 64 * h] = ra[h];
-        Bs0[ld_k * LDA + ld_r + 64 * h] = rb[h];
-    }
+    double2 pa0 = gA0[0], pa1 = gA1[0], pb0 = gB0[0], pb1 = gB1[0];
+    if (!k_in_range) { pa0 = zero2; pa1 = zero2; pb0 = zero2; pb1 = zero2; }
+    As0[st_off] = pa0;
+    As0[st_off + 64] = pa1;
+    Bs0[st_off] = pb0;
+    Bs0[st_off + 64] = pb1;
     __syncthreads();
 
     const int frag_k = lane >> 4, frag_r = lane & 15;
+    const int a_off = frag_k * LDA + wm * 64 + frag_r;
+    const int b_off = frag_k * LDA + wn * 32 + frag_r;
     for (int64_t kt = 0; kt < ktiles; ++kt) {
         const int cur = (int)(kt & 1);
-        const bool more = (kt + 1 < ktiles);
-        if (more) {
-            const int64_t off = (kt + 1) * BK;
-            for (int h = 0; h < 2; ++h) {
-                ra[h] = gA[h][off];
-                rb[h] = gB[h][off];
-            }
-        }
+        // prefetch the next k-tile into registers (the last iteration re-reads its own
+        // tile: branch-free, and nothing reads the buffer it is written to afterwards)
+        const int64_t off = min(kt + 1, ktiles - 1) * BK;
+        pa0 = gA0[off];
+        pa1 = gA1[off];
+        pb0 = gB0[off];
+        pb1 = gB1[off];
+        // keep the loads up here: hipcc otherwise sinks them to their first use (the LDS
+        // writes below) and every k-tile waits out a full HBM/L2 round trip
+        __builtin_amdgcn_sched_barrier(0);
         const double2* As = As0 + cur * BUF;
         const double2* Bs = Bs0 + cur * BUF;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             double2 a[4], b[2];
-            const int krow = (kk * 4 + frag_k) * LDA;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = As[krow + wm * 64 + m * 16 + frag_r];
+            for (int m = 0; m < 4; ++m) a[m] = As[kk * 4 * LDA + a_off + m * 16];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = Bs[krow + wn * 32 + n * 16 + frag_r];
+            for (int n = 0; n < 2; ++n) b[n] = Bs[kk * 4 * LDA + b_off + n * 16];
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -167,14 +169,12 @@ __global__ void __launch_bounds__(GRAM_THREADS, 2) gram_kernel(GramArgs args) {
                     accI[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[n].x, accI[m][n], 0, 0, 0);
             }
         }
-        if (more) {
-            double2* An = As0 + (cur ^ 1) * BUF;
-            double2* Bn = Bs0 + (cur ^ 1) * BUF;
-            for (int h = 0; h < 2; ++h) {
-                An[ld_k * LDA + ld_r + 64 * h] = ra[h];
-                Bn[ld_k * LDA + ld_r + 64 * h] = rb[h];
-            }
-        }
+        double2* An = As0 + (cur ^ 1) * BUF;
+        double2* Bn = Bs0 + (cur ^ 1) * BUF;
+        An[st_off] = pa0;
+        An[st_off + 64] = pa1;
+        Bn[st_off] = pb0;
+        Bn[st_off + 64] = pb1;
         __syncthreads();
     }
 
