@@ -1,36 +1,35 @@
 // Pairwise fidelity  K[i][j] = |sum_b conj(A[i][b]) B[j][b]|^2  on FP64 MFMA (gfx950).
 //
-// Psi rows are interleaved complex128, i.e. real vectors of length 2D.  With
-// a = A[i][b], c = B[j][b]:
+// Psi rows are interleaved complex128.  With a = A[i][b], c = B[j][b]:
 //     Re = sum  a.re*c.re + a.im*c.im          Im = sum  a.re*c.im - a.im*c.re
-// so one 16x16 output tile takes four v_mfma_f64_16x16x4_f64 per 4 amplitudes
-// (8 real flops per amplitude and entry = the algorithmic count of SURVEY.md 8d);
-// the MFMA k-slot of a lane (lane >> 4) is simply "which of the 4 amplitudes", and
-// each lane feeds the re and the im half of ONE 16-byte LDS read to the four MFMAs.
+// The MFMA k-slot of a lane (lane >> 4) is simply "which of 4 consecutive amplitudes",
+// and each lane feeds the re and im halves of ONE 16-byte LDS read to the MFMAs.
 //
-// Block tile 128 x 128, 8 waves (2 x 4), wave tile 64 x 32 (4 x 2 MFMA tiles, Re
-// and Im accumulators = 128 VGPRs), 2 waves per SIMD, one workgroup per CU.  A and
-// B tiles are staged global -> registers -> LDS, double buffered, one barrier per
-// BK amplitudes.  LDS images are k-major ([amplitude][row], 16-B elements, one
+// Two arithmetic forms per 16x16 tile and 4 amplitudes (v_mfma_f64_16x16x4_f64):
+//   4M  Re += ar*cr; Re += ai*ci; Im += ar*ci; Im += (-ai)*cr      4 MFMAs, 2 accumulators
+//   3M  P1 += ar*cr; P2 += ai*ci; P3 += (ar+ai)*(ci-cr)            3 MFMAs, 3 accumulators
+//       Re = P1 + P2, Im = P3 + P1 - P2   (Karatsuba; the sums ar+ai, ci-cr cost one
+//       VALU add per fragment).  Same result to ~1e-16; 25 % fewer matrix-core cycles.
+// The algorithmic count stays 8 real flops per amplitude and entry.
+//
+// A and B tiles are staged global -> registers -> LDS, double buffered, one barrier
+// per BK amplitudes.  LDS images are k-major ([amplitude][row], 16-B elements, one
 // element of padding per k row) so fragment reads are conflict free.
 //
-// Tile schedule: jobs are laid out in 16x16-tile super-tiles of 256 workgroups;
-// inside one, the 8 XCD labels (block id % 8) each own a 4 x 8 sub-block, so the
-// workgroups that share an L2 share A rows (8x) and B rows (4x).
+// Tile schedule: macro-tiles of 4 x 8 block tiles dealt round-robin to the 8 XCD labels
+// (block id % 8), so the 32 workgroups that share an L2 at any time share A rows (8x)
+// and B rows (4x); symmetric jobs list only macro-tiles that reach the diagonal.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "qk_common.h"
 
 namespace qk {
 
-constexpr int BM = 128, BN = 128, BK = 8;  // BK in amplitudes
-constexpr int GRAM_THREADS = 512;
-constexpr int LDA = BM + 1;                // padded k-row length (16-B elements)
-constexpr int SUPER = 16;                  // super-tile side, in tiles
-
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));  // native vector: stays in registers (HIP's double2 class arrays went to scratch)
 
 struct GramJobDev {
     const double2* A;
@@ -39,8 +38,7 @@ struct GramJobDev {
     double* KT;
     int64_t ma, nb, ldk, ldkt;
     int32_t flags;
-    int32_t tiles_m, tiles_n;  // 128-row tiles
-    int32_t sup_m, sup_n;      // super-tiles per side
+    int32_t tiles_m, tiles_n;  // block tiles
     int64_t block_begin;       // first workgroup of this job
 };
 
@@ -50,166 +48,335 @@ struct GramArgs {
     int64_t D;  // amplitudes per row
 };
 
-__global__ void __launch_bounds__(GRAM_THREADS, 2) gram_kernel(GramArgs args) {
-    extern __shared__ double2 smem[];  // [2 buffers][A | B][BK][LDA]
+// WAVES_M x WAVES_N waves, each TM x TN MFMA tiles of 16x16; BK amplitudes per barrier.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int BK, bool K3M>
+struct GramCfg {
+    static constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+    static constexpr int BM = WAVES_M * TM * 16;
+    static constexpr int BN = WAVES_N * TN * 16;
+    static constexpr int LDA = BM + 1;  // padded k-row lengths (16-B elements)
+    static constexpr int LDB = BN + 1;
+    static constexpr int BUF = BK * (LDA + LDB);
+    static constexpr int PA = BM * BK / THREADS;  // staged elements per thread and k-tile
+    static constexpr int PB = BN * BK / THREADS;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(double2);
+    static_assert(BM * BK % THREADS == 0 && BN * BK % THREADS == 0, "staging must divide evenly");
+    static_assert(BK % 8 == 0, "BK is a multiple of 8 amplitudes (128-byte runs)");
+};
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int BK, bool K3M>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4)
+gram_kernel(GramArgs args) {
+    using C = GramCfg<WAVES_M, WAVES_N, TM, TN, BK, K3M>;
+    constexpr int NACC = K3M ? 3 : 2;
+    extern __shared__ v2d smem[];  // [2 buffers][A: BK x LDA | B: BK x LDB]
     // ---- which tile ---------------------------------------------------------
     const int64_t bid = blockIdx.x;
-    int ji = 0;
-    for (int k = 1; k < args.n_jobs; ++k)
-        if (bid >= args.job[k].block_begin) ji = k;
-    const GramJobDev& J = args.job[ji];
+    // constant indices only: a dynamic index into the kernel-argument struct would copy it to scratch
+    GramJobDev J = args.job[0];
+#pragma unroll
+    for (int k = 1; k < QK_GRAM_MAX_JOBS; ++k)
+        if (k < args.n_jobs && bid >= args.job[k].block_begin) J = args.job[k];
+    // ---- tile schedule: macro-tiles of 4 x 8 block tiles, dealt round-robin to the 8 XCD labels.
+    // Workgroups with equal (block id % 8) share an XCD and its L2; the 32 that run there at a
+    // time form ONE macro-tile (4 A row blocks, 8 B row blocks), and the 8 XCDs walk neighbouring
+    // macro-tiles of the same 4-row band.  A symmetric job lists only macro-tiles that reach the
+    // diagonal, so every XCD gets the same number of them (+-1).
     const int64_t lb = bid - J.block_begin;
-    const int su = (int)(lb >> 8);
-    const int slot = (int)(lb & 255);
-    const int xcd = slot & 7, idx = slot >> 3;
-    const int sr = (xcd >> 1) * 4 + (idx >> 3);
-    const int sc = (xcd & 1) * 8 + (idx & 7);
+    const int xcd = (int)(lb & 7);
+    const int64_t seq = lb >> 3;                       // position in this XCD's stream
+    int64_t mt = (seq >> 5) * 8 + xcd;                 // macro-tile index within the job
+    const int tin = (int)(seq & 31);
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
-    int SI, SJ;
-    if (sym) {  // su enumerates super-tiles (I, J >= I) row by row
-        int I = 0, rem = su, rowlen = J.sup_n;
-        while (rem >= rowlen) { rem -= rowlen; --rowlen; ++I; }
-        SI = I;
-        SJ = I + rem;
+    const int C8 = (J.tiles_n + 7) >> 3, R4 = (J.tiles_m + 3) >> 2;
+    int R = 0, Cg;
+    if (sym) {
+        for (;; ++R) {
+            if (R >= R4) return;
+            const int cg0 = (R * C::BM) / (2 * C::BN);  // first column group that reaches the diagonal
+            const int cnt = C8 - cg0;
+            if (cnt <= 0) return;
+            if (mt < cnt) { Cg = cg0 + (int)mt; break; }
+            mt -= cnt;
+        }
     } else {
-        SI = su / J.sup_n;
-        SJ = su % J.sup_n;
+        R = (int)(mt / C8);
+        Cg = (int)(mt % C8);
+        if (R >= R4) return;
     }
-    const int ti = SI * SUPER + sr, tj = SJ * SUPER + sc;
-    if (ti >= J.tiles_m || tj >= J.tiles_n || (sym && tj < ti)) return;
+    const int ti = R * 4 + (tin >> 3), tj = Cg * 8 + (tin & 7);
+    // a symmetric job only needs tiles that reach the diagonal or lie above it
+    if (ti >= J.tiles_m || tj >= J.tiles_n || (sym && (int64_t)(tj + 1) * C::BN <= (int64_t)ti * C::BM)) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int64_t D = args.D;
-    const int64_t row0 = (int64_t)ti * BM, col0 = (int64_t)tj * BN;
+    const int64_t row0 = (int64_t)ti * C::BM, col0 = (int64_t)tj * C::BN;
+    const int64_t ma = J.ma, nb = J.nb;
+    const v2d* __restrict__ Ag = (const v2d*)J.A;
+    const v2d* __restrict__ Bg = (const v2d*)J.B;
 
-    // ---- global -> register staging map: lanes 0..7 cover 128 contiguous bytes of a row
-    const int ld_k = tid & 7;
-    const int ld_r = tid >> 3;  // 0..63 (+64 for the second element)
-    // clamp rows: values of clamped rows land in LDS rows whose results are never stored
-    const int64_t ra0_ = min(row0 + ld_r, J.ma - 1), ra1_ = min(row0 + ld_r + 64, J.ma - 1);
-    const int64_t rb0_ = min(col0 + ld_r, J.nb - 1), rb1_ = min(col0 + ld_r + 64, J.nb - 1);
-    const bool k_in_range = ld_k < D;  // D < BK only for circuits under 3 qubits
-    const int ldk_c = k_in_range ? ld_k : 0;
-    const double2* gA0 = J.A + ra0_ * D + ldk_c;
-    const double2* gA1 = J.A + ra1_ * D + ldk_c;
-    const double2* gB0 = J.B + rb0_ * D + ldk_c;
-    const double2* gB1 = J.B + rb1_ * D + ldk_c;
-
-    double2* As0 = smem;
-    double2* Bs0 = smem + BK * LDA;
-    constexpr int BUF = 2 * BK * LDA;
-    const int st_off = ld_k * LDA + ld_r;
-
-    v4d accR[4][2], accI[4][2];
+    // ---- global -> register staging map: BK consecutive lanes cover BK*16 contiguous bytes of a row.
+    // Rows past the end are clamped: their values land in LDS rows whose results are never stored.
+    const bool k_in_range = (tid % BK) < D;  // D < BK only for circuits under 3 qubits
+    const int ld_k = k_in_range ? (tid % BK) : 0;
+    const v2d* gA[C::PA];
+    const v2d* gB[C::PB];
+    int sA[C::PA], sB[C::PB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int p = 0; p < C::PA; ++p) {
+        const int r = (tid + p * C::THREADS) / BK;
+        gA[p] = Ag + min(row0 + r, ma - 1) * D + ld_k;
+        sA[p] = (tid % BK) * C::LDA + r;
+    }
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            accR[m][n] = (v4d){0, 0, 0, 0};
-            accI[m][n] = (v4d){0, 0, 0, 0};
-        }
+    for (int p = 0; p < C::PB; ++p) {
+        const int r = (tid + p * C::THREADS) / BK;
+        gB[p] = Bg + min(col0 + r, nb - 1) * D + ld_k;
+        sB[p] = BK * C::LDA + (tid % BK) * C::LDB + r;
+    }
+
+    v4d acc[NACC][TM][TN];
+#pragma unroll
+    for (int c = 0; c < NACC; ++c)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[c][m][n] = (v4d){0, 0, 0, 0};
 
     const int64_t ktiles = (D + BK - 1) / BK;
-    const double2 zero2 = make_double2(0.0, 0.0);
+    const v2d zero2 = (v2d){0.0, 0.0};
+    v2d pa[C::PA], pb[C::PB];
     // prologue: tile 0 -> LDS buffer 0
-    double2 pa0 = gA0[0], pa1 = gA1[0], pb0 = gB0[0], pb1 = gB1[0];
-    if (!k_in_range) { pa0 = zero2; pa1 = zero2; pb0 = zero2; pb1 = zero2; }
-    As0[st_off] = pa0;
-    As0[st_off + 64] = pa1;
-    Bs0[st_off] = pb0;
-    Bs0[st_off + 64] = pb1;
+#pragma unroll
+    for (int p = 0; p < C::PA; ++p) pa[p] = k_in_range ? gA[p][0] : zero2;
+#pragma unroll
+    for (int p = 0; p < C::PB; ++p) pb[p] = k_in_range ? gB[p][0] : zero2;
+#pragma unroll
+    for (int p = 0; p < C::PA; ++p) smem[sA[p]] = pa[p];
+#pragma unroll
+    for (int p = 0; p < C::PB; ++p) smem[sB[p]] = pb[p];
     __syncthreads();
 
     const int frag_k = lane >> 4, frag_r = lane & 15;
-    const int a_off = frag_k * LDA + wm * 64 + frag_r;
-    const int b_off = frag_k * LDA + wn * 32 + frag_r;
-    for (int64_t kt = 0; kt < ktiles; ++kt) {
-        const int cur = (int)(kt & 1);
-        // prefetch the next k-tile into registers (the last iteration re-reads its own
-        // tile: branch-free, and nothing reads the buffer it is written to afterwards)
-        const int64_t off = min(kt + 1, ktiles - 1) * BK;
-        pa0 = gA0[off];
-        pa1 = gA1[off];
-        pb0 = gB0[off];
-        pb1 = gB1[off];
-        // keep the loads up here: hipcc otherwise sinks them to their first use (the LDS
-        // writes below) and every k-tile waits out a full HBM/L2 round trip
-        __builtin_amdgcn_sched_barrier(0);
-        const double2* As = As0 + cur * BUF;
-        const double2* Bs = Bs0 + cur * BUF;
+    const int a_off = frag_k * C::LDA + wm * (TM * 16) + frag_r;
+    const int b_off = BK * C::LDA + frag_k * C::LDB + wn * (TN * 16) + frag_r;
+    constexpr int KS = BK / 4;  // MFMA k-steps per k-tile
+    if constexpr (K3M) {
+        // Software pipeline: the fragments of k-step s+1 are read from LDS after the P1/P2 MFMAs of
+        // step s have been issued (their a/b registers are dead by then) and before its P3 MFMAs,
+        // so the LDS latency hides behind TM*TN MFMAs (64 cycles each) -- also across the barrier.
+        v2d a[TM], b[TN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double2 a[4], b[2];
+        for (int m = 0; m < TM; ++m) a[m] = smem[a_off + m * 16];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = As[kk * 4 * LDA + a_off + m * 16];
+        for (int n = 0; n < TN; ++n) b[n] = smem[b_off + n * 16];
+        for (int64_t kt = 0; kt < ktiles; ++kt) {
+            const int cur = (int)(kt & 1);
+            const int64_t off = min(kt + 1, ktiles - 1) * BK;  // last tile re-reads itself (branch-free)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = Bs[kk * 4 * LDA + b_off + n * 16];
+            for (int p = 0; p < C::PA; ++p) pa[p] = gA[p][off];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int p = 0; p < C::PB; ++p) pb[p] = gB[p][off];
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads at the top of the k-tile
+            const v2d* S = smem + cur * C::BUF;
+            v2d* Sn = smem + (cur ^ 1) * C::BUF;
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    accR[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, accR[m][n], 0, 0, 0);
+            for (int kk = 0; kk < KS; ++kk) {
+                double sa[TM], db[TN];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < TM; ++m) sa[m] = a[m].x + a[m].y;
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    accI[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].y, accI[m][n], 0, 0, 0);
+                for (int n = 0; n < TN; ++n) db[n] = b[n].y - b[n].x;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    accR[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, accR[m][n], 0, 0, 0);
+                    for (int n = 0; n < TN; ++n)
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const double nai = -a[m].y;
+                for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    accI[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[n].x, accI[m][n], 0, 0, 0);
+                    for (int n = 0; n < TN; ++n)
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < KS - 1) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) a[m] = S[(kk + 1) * 4 * C::LDA + a_off + m * 16];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) b[n] = S[(kk + 1) * 4 * C::LDB + b_off + n * 16];
+                } else {
+#pragma unroll
+                    for (int p = 0; p < C::PA; ++p) Sn[sA[p]] = pa[p];
+#pragma unroll
+                    for (int p = 0; p < C::PB; ++p) Sn[sB[p]] = pb[p];
+                    __syncthreads();
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) a[m] = Sn[a_off + m * 16];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) b[n] = Sn[b_off + n * 16];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[2][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[m], db[n], acc[2][m][n], 0, 0, 0);
             }
         }
-        double2* An = As0 + (cur ^ 1) * BUF;
-        double2* Bn = Bs0 + (cur ^ 1) * BUF;
-        An[st_off] = pa0;
-        An[st_off + 64] = pa1;
-        Bn[st_off] = pb0;
-        Bn[st_off + 64] = pb1;
-        __syncthreads();
+    } else {
+        for (int64_t kt = 0; kt < ktiles; ++kt) {
+            const int cur = (int)(kt & 1);
+            // prefetch the next k-tile into registers (the last iteration re-reads its own
+            // tile: branch-free, and nothing reads the buffer it is written to afterwards)
+            const int64_t off = min(kt + 1, ktiles - 1) * BK;
+#pragma unroll
+            for (int p = 0; p < C::PA; ++p) pa[p] = gA[p][off];
+#pragma unroll
+            for (int p = 0; p < C::PB; ++p) pb[p] = gB[p][off];
+            // keep the loads up here: hipcc otherwise sinks them to their first use (the LDS
+            // writes below) and every k-tile waits out a full HBM/L2 round trip
+            __builtin_amdgcn_sched_barrier(0);
+            const v2d* S = smem + cur * C::BUF;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                v2d a[TM], b[TN];
+#pragma unroll
+                for (int m = 0; m < TM; ++m) a[m] = S[kk * 4 * C::LDA + a_off + m * 16];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) b[n] = S[kk * 4 * C::LDB + b_off + n * 16];
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].y, acc[1][m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[0][m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const double nai = -a[m].y;
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[n].x, acc[1][m][n], 0, 0, 0);
+                }
+            }
+            v2d* Sn = smem + (cur ^ 1) * C::BUF;
+#pragma unroll
+            for (int p = 0; p < C::PA; ++p) Sn[sA[p]] = pa[p];
+#pragma unroll
+            for (int p = 0; p < C::PB; ++p) Sn[sB[p]] = pb[p];
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: |.|^2, direct + mirrored stores ----------------------------
     // f64 16x16x4 result layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-    const bool diag_tile = sym && (ti == tj);
+    double* __restrict__ Kp = J.K;
+    double* __restrict__ KTp = J.KT;
+    const int64_t ldk = J.ldk, ldkt = J.ldkt;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t i = row0 + wm * 64 + m * 16 + (lane >> 4) + 4 * r;
-                const int64_t j = col0 + wn * 32 + n * 16 + (lane & 15);
-                if (i >= J.ma || j >= J.nb) continue;
-                const double re = accR[m][n][r], im = accI[m][n][r];
+                const int64_t i = row0 + wm * (TM * 16) + m * 16 + (lane >> 4) + 4 * r;
+                const int64_t j = col0 + wn * (TN * 16) + n * 16 + (lane & 15);
+                if (i >= ma || j >= nb) continue;
+                double re, im;
+                if constexpr (K3M) {
+                    re = acc[0][m][n][r] + acc[1][m][n][r];
+                    im = acc[2][m][n][r] + (acc[0][m][n][r] - acc[1][m][n][r]);
+                } else {
+                    re = acc[0][m][n][r];
+                    im = acc[1][m][n][r];
+                }
                 double v = fma(re, re, im * im);
-                if (diag_tile) {
-                    if (i > j) continue;      // lower half of a diagonal tile comes from its mirror
+                if (sym) {
+                    if (i > j) continue;      // below the diagonal: written by the mirror store
                     if (i == j) v = 1.0;      // identical statevectors stay exactly 1
                 }
-                J.K[i * J.ldk + j] = v;
-                if (sym && i != j) J.K[j * J.ldk + i] = v;
-                if (J.KT) J.KT[j * J.ldkt + i] = v;
+                Kp[i * ldk + j] = v;
+                if (sym && i != j) Kp[j * ldk + i] = v;
+                if (KTp) KTp[j * ldkt + i] = v;
             }
 }
 
+// ---- variants ------------------------------------------------------------------
+struct Variant {
+    const char* name;
+    int bm, bn, threads;
+    size_t lds;
+    const void* fn;
+    void (*launch)(const GramArgs&, unsigned, hipStream_t);
+};
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int BK, bool K3M>
+void launch_variant(const GramArgs& args, unsigned blocks, hipStream_t stream) {
+    using C = GramCfg<WAVES_M, WAVES_N, TM, TN, BK, K3M>;
+    hipLaunchKernelGGL((gram_kernel<WAVES_M, WAVES_N, TM, TN, BK, K3M>), dim3(blocks), dim3(C::THREADS), C::LDS_BYTES,
+                       stream, args);
+}
+
+#define QK_VARIANT(NAME, WM, WN, TM, TN, BK, K3M)                                                          \
+    Variant {                                                                                              \
+        NAME, GramCfg<WM, WN, TM, TN, BK, K3M>::BM, GramCfg<WM, WN, TM, TN, BK, K3M>::BN,                  \
+            GramCfg<WM, WN, TM, TN, BK, K3M>::THREADS, GramCfg<WM, WN, TM, TN, BK, K3M>::LDS_BYTES,        \
+            (const void*)gram_kernel<WM, WN, TM, TN, BK, K3M>, launch_variant<WM, WN, TM, TN, BK, K3M>     \
+    }
+
+static const Variant kVariants[] = {
+    QK_VARIANT("4m_128x128_w8_bk8", 2, 4, 4, 2, 8, false),
+    QK_VARIANT("4m_128x128_w8_bk16", 2, 4, 4, 2, 16, false),
+    QK_VARIANT("3m_96x128_w8_bk16", 2, 4, 3, 2, 16, true),
+    QK_VARIANT("3m_128x96_w8_bk16", 4, 2, 2, 3, 16, true),
+    QK_VARIANT("3m_128x128_w4_bk8", 2, 2, 4, 4, 8, true),
+    QK_VARIANT("4m_128x128_w4_bk8", 2, 2, 4, 4, 8, false),
+    QK_VARIANT("4m_128x128_w4_bk16", 2, 2, 4, 4, 16, false),
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+constexpr int kDefaultVariant = 2;  // 3m_96x128_w8_bk16: fastest measured (tools/gram_ab.py)
+
+static int g_variant = -1;
+static bool g_attr_set[kNumVariants] = {false};
+
+static int pick_variant() {
+    if (g_variant >= 0) return g_variant;
+    g_variant = kDefaultVariant;
+    if (const char* e = std::getenv("QK_GRAM_VARIANT")) {
+        for (int v = 0; v < kNumVariants; ++v)
+            if (std::strcmp(e, kVariants[v].name) == 0) g_variant = v;
+    }
+    return g_variant;
+}
+
 }  // namespace qk
+
+// Development hook (not in the public header): select a kernel variant by name for A/B timing.
+extern "C" int qk_gram_set_variant(const char* name) {
+    using namespace qk;
+    for (int v = 0; v < kNumVariants; ++v)
+        if (name && std::strcmp(name, kVariants[v].name) == 0) {
+            g_variant = v;
+            return QK_OK;
+        }
+    return fail(QK_ERR_INVALID, "qk_gram_set_variant: unknown variant");
+}
 
 extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
     using namespace qk;
     if (!jobs || n_jobs < 1 || n_jobs > QK_GRAM_MAX_JOBS)
         return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: need 1..16 jobs");
-    if (D < 1) return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: D must be >= 1");
-    if (D >= BK && (D % BK) != 0) return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: D must be a power of two");
+    if (D < 1 || (D & (D - 1)) != 0) return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: D must be a power of two");
+    const Variant& V = kVariants[pick_variant()];
     GramArgs args;
     std::memset(&args, 0, sizeof(args));
     args.D = D;
@@ -232,24 +399,31 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
         d.KT = j.KT;
         d.ma = j.ma; d.nb = j.nb; d.ldk = j.ldk; d.ldkt = j.ldkt;
         d.flags = j.flags;
-        d.tiles_m = (int32_t)((j.ma + BM - 1) / BM);
-        d.tiles_n = (int32_t)((j.nb + BN - 1) / BN);
-        d.sup_m = (d.tiles_m + SUPER - 1) / SUPER;
-        d.sup_n = (d.tiles_n + SUPER - 1) / SUPER;
+        d.tiles_m = (int32_t)((j.ma + V.bm - 1) / V.bm);
+        d.tiles_n = (int32_t)((j.nb + V.bn - 1) / V.bn);
         d.block_begin = blocks;
-        const int64_t nsup = sym ? (int64_t)d.sup_n * (d.sup_n + 1) / 2 : (int64_t)d.sup_m * d.sup_n;
-        blocks += nsup * 256;
+        const int C8 = (d.tiles_n + 7) / 8, R4 = (d.tiles_m + 3) / 4;
+        int64_t macros = 0;
+        if (sym) {
+            for (int R = 0; R < R4; ++R) {
+                const int cnt = C8 - (R * V.bm) / (2 * V.bn);
+                if (cnt <= 0) break;
+                macros += cnt;
+            }
+        } else {
+            macros = (int64_t)R4 * C8;
+        }
+        blocks += ((macros + 7) / 8) * 256;  // whole rounds of 8 macro-tiles keep block_begin % 256 == 0
     }
     if (nj == 0) return QK_OK;
     args.n_jobs = nj;
     if (blocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, "qk_gram_jobs_dev: too many tiles; split the call");
-    const size_t lds = (size_t)2 * 2 * BK * LDA * sizeof(double2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QK_HIP(hipFuncSetAttribute((const void*)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    const int vi = pick_variant();
+    if (!g_attr_set[vi]) {
+        QK_HIP(hipFuncSetAttribute(V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds));
+        g_attr_set[vi] = true;
     }
-    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)blocks), dim3(GRAM_THREADS), lds, (hipStream_t)stream, args);
+    V.launch(args, (unsigned)blocks, (hipStream_t)stream);
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
