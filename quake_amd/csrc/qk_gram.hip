@@ -46,7 +46,84 @@ struct GramArgs {
     GramJobDev job[QK_GRAM_MAX_JOBS];
     int n_jobs;
     int64_t D;  // amplitudes per row
+    int dbg;    // diagnostics only (tools/gram_ab.py): 1 = no global loads / LDS writes, 2 = also no barrier
 };
+
+// Which block tile does this workgroup compute?  Returns false for padding workgroups.
+// Tile schedule: macro-tiles of 4 x 8 block tiles, dealt round-robin to the 8 XCD labels.
+// Workgroups with equal (block id % 8) share an XCD and its L2; the 32 that run there at a
+// time form ONE macro-tile (4 A row blocks, 8 B row blocks), and the 8 XCDs walk neighbouring
+// macro-tiles of the same 4-row band.  A symmetric job lists only macro-tiles that reach the
+// diagonal, so every XCD gets the same number of them (+-1).
+__device__ __forceinline__ bool gram_locate(const GramArgs& args, int BM, int BN, GramJobDev& J, int& ti, int& tj) {
+    const int64_t bid = blockIdx.x;
+    // constant indices only: a dynamic index into the kernel-argument struct would copy it to scratch
+    J = args.job[0];
+#pragma unroll
+    for (int k = 1; k < QK_GRAM_MAX_JOBS; ++k)
+        if (k < args.n_jobs && bid >= args.job[k].block_begin) J = args.job[k];
+    const int64_t lb = bid - J.block_begin;
+    const int xcd = (int)(lb & 7);
+    const int64_t seq = lb >> 3;                       // position in this XCD's stream
+    int64_t mt = (seq >> 5) * 8 + xcd;                 // macro-tile index within the job
+    const int tin = (int)(seq & 31);
+    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+    const int C8 = (J.tiles_n + 7) >> 3, R4 = (J.tiles_m + 3) >> 2;
+    int R = 0, Cg;
+    if (sym) {
+        for (;; ++R) {
+            if (R >= R4) return false;
+            const int cg0 = (R * BM) / (2 * BN);  // first column group that reaches the diagonal
+            const int cnt = C8 - cg0;
+            if (cnt <= 0) return false;
+            if (mt < cnt) { Cg = cg0 + (int)mt; break; }
+            mt -= cnt;
+        }
+    } else {
+        R = (int)(mt / C8);
+        Cg = (int)(mt % C8);
+        if (R >= R4) return false;
+    }
+    ti = R * 4 + (tin >> 3);
+    tj = Cg * 8 + (tin & 7);
+    // a symmetric job only needs tiles that reach the diagonal or lie above it
+    return !(ti >= J.tiles_m || tj >= J.tiles_n || (sym && (int64_t)(tj + 1) * BN <= (int64_t)ti * BM));
+}
+
+// |.|^2 and the stores.  f64 16x16x4 result layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
+template <int TM, int TN, bool K3M, int NACC>
+__device__ __forceinline__ void gram_epilogue(v4d (&acc)[NACC][TM][TN], const GramJobDev& J, int64_t wrow0,
+                                              int64_t wcol0, int lane, bool sym) {
+    double* __restrict__ Kp = J.K;
+    double* __restrict__ KTp = J.KT;
+    const int64_t ldk = J.ldk, ldkt = J.ldkt, ma = J.ma, nb = J.nb;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = wrow0 + m * 16 + (lane >> 4) + 4 * r;
+                const int64_t j = wcol0 + n * 16 + (lane & 15);
+                if (i >= ma || j >= nb) continue;
+                double re, im;
+                if constexpr (K3M) {
+                    re = acc[0][m][n][r] + acc[1][m][n][r];
+                    im = acc[2][m][n][r] + (acc[0][m][n][r] - acc[1][m][n][r]);
+                } else {
+                    re = acc[0][m][n][r];
+                    im = acc[1][m][n][r];
+                }
+                double v = fma(re, re, im * im);
+                if (sym) {
+                    if (i > j) continue;      // below the diagonal: written by the mirror store
+                    if (i == j) v = 1.0;      // identical statevectors stay exactly 1 (SURVEY 8a A5)
+                }
+                Kp[i * ldk + j] = v;
+                if (sym && i != j) Kp[j * ldk + i] = v;
+                if (KTp) KTp[j * ldkt + i] = v;
+            }
+}
 
 // WAVES_M x WAVES_N waves, each TM x TN MFMA tiles of 16x16; BK amplitudes per barrier.
 template <int WAVES_M, int WAVES_N, int TM, int TN, int BK, bool K3M>
@@ -70,43 +147,10 @@ gram_kernel(GramArgs args) {
     using C = GramCfg<WAVES_M, WAVES_N, TM, TN, BK, K3M>;
     constexpr int NACC = K3M ? 3 : 2;
     extern __shared__ v2d smem[];  // [2 buffers][A: BK x LDA | B: BK x LDB]
-    // ---- which tile ---------------------------------------------------------
-    const int64_t bid = blockIdx.x;
-    // constant indices only: a dynamic index into the kernel-argument struct would copy it to scratch
-    GramJobDev J = args.job[0];
-#pragma unroll
-    for (int k = 1; k < QK_GRAM_MAX_JOBS; ++k)
-        if (k < args.n_jobs && bid >= args.job[k].block_begin) J = args.job[k];
-    // ---- tile schedule: macro-tiles of 4 x 8 block tiles, dealt round-robin to the 8 XCD labels.
-    // Workgroups with equal (block id % 8) share an XCD and its L2; the 32 that run there at a
-    // time form ONE macro-tile (4 A row blocks, 8 B row blocks), and the 8 XCDs walk neighbouring
-    // macro-tiles of the same 4-row band.  A symmetric job lists only macro-tiles that reach the
-    // diagonal, so every XCD gets the same number of them (+-1).
-    const int64_t lb = bid - J.block_begin;
-    const int xcd = (int)(lb & 7);
-    const int64_t seq = lb >> 3;                       // position in this XCD's stream
-    int64_t mt = (seq >> 5) * 8 + xcd;                 // macro-tile index within the job
-    const int tin = (int)(seq & 31);
+    GramJobDev J;
+    int ti, tj;
+    if (!gram_locate(args, C::BM, C::BN, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
-    const int C8 = (J.tiles_n + 7) >> 3, R4 = (J.tiles_m + 3) >> 2;
-    int R = 0, Cg;
-    if (sym) {
-        for (;; ++R) {
-            if (R >= R4) return;
-            const int cg0 = (R * C::BM) / (2 * C::BN);  // first column group that reaches the diagonal
-            const int cnt = C8 - cg0;
-            if (cnt <= 0) return;
-            if (mt < cnt) { Cg = cg0 + (int)mt; break; }
-            mt -= cnt;
-        }
-    } else {
-        R = (int)(mt / C8);
-        Cg = (int)(mt % C8);
-        if (R >= R4) return;
-    }
-    const int ti = R * 4 + (tin >> 3), tj = Cg * 8 + (tin & 7);
-    // a symmetric job only needs tiles that reach the diagonal or lie above it
-    if (ti >= J.tiles_m || tj >= J.tiles_n || (sym && (int64_t)(tj + 1) * C::BN <= (int64_t)ti * C::BM)) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -175,10 +219,12 @@ gram_kernel(GramArgs args) {
         for (int64_t kt = 0; kt < ktiles; ++kt) {
             const int cur = (int)(kt & 1);
             const int64_t off = min(kt + 1, ktiles - 1) * BK;  // last tile re-reads itself (branch-free)
+            if (args.dbg == 0) {
 #pragma unroll
             for (int p = 0; p < C::PA; ++p) pa[p] = gA[p][off];
 #pragma unroll
             for (int p = 0; p < C::PB; ++p) pb[p] = gB[p][off];
+            }
             __builtin_amdgcn_sched_barrier(0);  // keep the loads at the top of the k-tile
             const v2d* S = smem + cur * C::BUF;
             v2d* Sn = smem + (cur ^ 1) * C::BUF;
@@ -206,11 +252,13 @@ gram_kernel(GramArgs args) {
 #pragma unroll
                     for (int n = 0; n < TN; ++n) b[n] = S[(kk + 1) * 4 * C::LDB + b_off + n * 16];
                 } else {
+                    if (args.dbg == 0) {
 #pragma unroll
                     for (int p = 0; p < C::PA; ++p) Sn[sA[p]] = pa[p];
 #pragma unroll
                     for (int p = 0; p < C::PB; ++p) Sn[sB[p]] = pb[p];
-                    __syncthreads();
+                    }
+                    if (args.dbg < 2) __syncthreads();
 #pragma unroll
                     for (int m = 0; m < TM; ++m) a[m] = Sn[a_off + m * 16];
 #pragma unroll
@@ -277,43 +325,208 @@ gram_kernel(GramArgs args) {
         }
     }
 
-    // ---- epilogue: |.|^2, direct + mirrored stores ----------------------------
-    // f64 16x16x4 result layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-    double* __restrict__ Kp = J.K;
-    double* __restrict__ KTp = J.KT;
-    const int64_t ldk = J.ldk, ldkt = J.ldkt;
+    gram_epilogue<TM, TN, K3M>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
+}
+
+// ---- LDS-DMA variant ---------------------------------------------------------------
+// Same tiling and arithmetic, but the A/B tiles go HBM/L2 -> LDS directly with
+// global_load_lds_dwordx4 (no staging registers, no ds_write, no VGPR write-back).
+// The DMA writes LDS linearly (wave-uniform base + lane * 16 B), so the LDS image is
+// row-major [row][16 slots] with 256-byte rows, and the bank swizzle lives in the SOURCE
+// address: slot s of row r holds amplitude k = s ^ (r & 15).  One wave instruction fills
+// 4 rows from 4 x 256 contiguous bytes of Psi; a fragment read (16 rows x one k-slot per
+// 16-lane group) then touches 16 different slots = all 64 banks once: conflict free.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool K3M>
+struct GramDmaCfg {
+    static constexpr int BK = 16;
+    static constexpr int WAVES = WAVES_M * WAVES_N;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int BM = WAVES_M * TM * 16;
+    static constexpr int BN = WAVES_N * TN * 16;
+    static constexpr int BUF = (BM + BN) * BK;          // elements (16 B) per buffer
+    static constexpr int NA = BM / 4 / WAVES;           // DMA instructions per wave and k-tile
+    static constexpr int NB = BN / 4 / WAVES;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF * 16;
+    static_assert(BM % (4 * WAVES) == 0 && BN % (4 * WAVES) == 0, "rows must split evenly over the waves");
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool K3M>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4)
+gram_dma_kernel(GramArgs args) {
+    using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, K3M>;
+    constexpr int NACC = K3M ? 3 : 2;
+    constexpr int KS = 4;  // BK / 4
+    extern __shared__ v2d smem[];  // [2 buffers][A: BM x 16 | B: BN x 16]
+    GramJobDev J;
+    int ti, tj;
+    if (!gram_locate(args, C::BM, C::BN, J, ti, tj)) return;
+    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int64_t D = args.D;
+    const int64_t row0 = (int64_t)ti * C::BM, col0 = (int64_t)tj * C::BN;
+    const int64_t ma = J.ma, nb = J.nb;
+    const v2d* __restrict__ Ag = (const v2d*)J.A;
+    const v2d* __restrict__ Bg = (const v2d*)J.B;
+
+    // DMA source pointers (per lane) and LDS destinations (per wave) of this wave's instructions
+    const v2d* gA[C::NA];
+    const v2d* gB[C::NB];
 #pragma unroll
-    for (int m = 0; m < TM; ++m)
+    for (int j = 0; j < C::NA; ++j) {
+        const int row = 4 * (wave + C::WAVES * j) + (lane >> 4);
+        gA[j] = Ag + min(row0 + row, ma - 1) * D + ((lane & 15) ^ (row & 15));
+    }
 #pragma unroll
-        for (int n = 0; n < TN; ++n)
+    for (int j = 0; j < C::NB; ++j) {
+        const int row = 4 * (wave + C::WAVES * j) + (lane >> 4);
+        gB[j] = Bg + min(col0 + row, nb - 1) * D + ((lane & 15) ^ (row & 15));
+    }
+    // DMA instruction e of this wave (A first, then B); `part` < 0 issues all of them, otherwise only
+    // those assigned to k-step `part`: spread over the first KS-1 k-steps so that the ~100-cycle issue
+    // cost of each lands between MFMAs instead of in front of them, and the last ones still have a
+    // quarter k-tile to land before the barrier.
+    auto issue_dma = [&](int buf, int64_t off, int part) {
+        v2d* base = smem + buf * C::BUF;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t i = row0 + wm * (TM * 16) + m * 16 + (lane >> 4) + 4 * r;
-                const int64_t j = col0 + wn * (TN * 16) + n * 16 + (lane & 15);
-                if (i >= ma || j >= nb) continue;
-                double re, im;
-                if constexpr (K3M) {
-                    re = acc[0][m][n][r] + acc[1][m][n][r];
-                    im = acc[2][m][n][r] + (acc[0][m][n][r] - acc[1][m][n][r]);
-                } else {
-                    re = acc[0][m][n][r];
-                    im = acc[1][m][n][r];
-                }
-                double v = fma(re, re, im * im);
-                if (sym) {
-                    if (i > j) continue;      // below the diagonal: written by the mirror store
-                    if (i == j) v = 1.0;      // identical statevectors stay exactly 1 (SURVEY 8a A5)
-                }
-                Kp[i * ldk + j] = v;
-                if (sym && i != j) Kp[j * ldk + i] = v;
-                if (KTp) KTp[j * ldkt + i] = v;
+        for (int e = 0; e < C::NA + C::NB; ++e) {
+            if (part >= 0 && (e % 3) != part) continue;
+            if (e < C::NA) {
+                const int j = e < C::NA ? e : 0;
+                __builtin_amdgcn_global_load_lds((gptr_t)(gA[j] + off), (lptr_t)(base + (wave + C::WAVES * j) * 64), 16, 0, 0);
+            } else {
+                const int j = e >= C::NA ? e - C::NA : 0;
+                __builtin_amdgcn_global_load_lds((gptr_t)(gB[j] + off),
+                                                 (lptr_t)(base + C::BM * 16 + (wave + C::WAVES * j) * 64), 16, 0, 0);
             }
+        }
+    };
+
+    v4d acc[NACC][TM][TN];
+#pragma unroll
+    for (int c = 0; c < NACC; ++c)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[c][m][n] = (v4d){0, 0, 0, 0};
+
+    const int64_t ktiles = D / C::BK;
+    issue_dma(0, 0, -1);
+    __syncthreads();
+
+    // fragment addresses: element (row * 16 + ((4 kk + lane>>4) ^ (lane & 15)))
+    const int frag_k = lane >> 4, frag_r = lane & 15;
+    const int a_row = (wm * (TM * 16) + frag_r) * 16;
+    const int b_row = C::BM * 16 + (wn * (TN * 16) + frag_r) * 16;
+    int xs[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) xs[kk] = (4 * kk + frag_k) ^ frag_r;
+
+    v2d a[TM], b[TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[m] = smem[a_row + m * 256 + xs[0]];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) b[n] = smem[b_row + n * 256 + xs[0]];
+    for (int64_t kt = 0; kt < ktiles; ++kt) {
+        const int cur = (int)(kt & 1);
+        // next k-tile straight into the other buffer (nobody reads it during this k-tile);
+        // the last iteration re-reads its own tile: branch-free and harmless
+        const int64_t noff = min(kt + 1, ktiles - 1) * C::BK;
+        const v2d* S = smem + cur * C::BUF;
+        const v2d* Sn = smem + (cur ^ 1) * C::BUF;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if constexpr (K3M) {
+                // software pipeline: fragments of the next k-step are read after P1/P2 have been
+                // issued (a, b are dead then) and before P3, also across the barrier
+                double sa[TM], db[TN];
+#pragma unroll
+                for (int m = 0; m < TM; ++m) sa[m] = a[m].x + a[m].y;
+#pragma unroll
+                for (int n = 0; n < TN; ++n) db[n] = b[n].y - b[n].x;
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (args.dbg == 0 && kk < 3) issue_dma(cur ^ 1, noff, kk);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < KS - 1) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) a[m] = S[a_row + m * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) b[n] = S[b_row + n * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+                } else {
+                    if (args.dbg < 2) __syncthreads();
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) a[m] = Sn[a_row + m * 256 + xs[0]];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) b[n] = Sn[b_row + n * 256 + xs[0]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[2][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[m], db[n], acc[2][m][n], 0, 0, 0);
+            } else {
+                if (args.dbg == 0 && kk < 3) issue_dma(cur ^ 1, noff, kk);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].y, acc[1][m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[0][m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const double nai = -a[m].y;
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[n].x, acc[1][m][n], 0, 0, 0);
+                }
+                if (kk < KS - 1) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) a[m] = S[a_row + m * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) b[n] = S[b_row + n * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+                } else {
+                    __syncthreads();
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) a[m] = Sn[a_row + m * 256 + xs[0]];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) b[n] = Sn[b_row + n * 256 + xs[0]];
+                }
+            }
+        }
+    }
+    gram_epilogue<TM, TN, K3M>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
 }
 
 // ---- variants ------------------------------------------------------------------
 struct Variant {
     const char* name;
-    int bm, bn, threads;
+    int bm, bn, threads, min_d;
     size_t lds;
     const void* fn;
     void (*launch)(const GramArgs&, unsigned, hipStream_t);
@@ -329,8 +542,22 @@ void launch_variant(const GramArgs& args, unsigned blocks, hipStream_t stream) {
 #define QK_VARIANT(NAME, WM, WN, TM, TN, BK, K3M)                                                          \
     Variant {                                                                                              \
         NAME, GramCfg<WM, WN, TM, TN, BK, K3M>::BM, GramCfg<WM, WN, TM, TN, BK, K3M>::BN,                  \
-            GramCfg<WM, WN, TM, TN, BK, K3M>::THREADS, GramCfg<WM, WN, TM, TN, BK, K3M>::LDS_BYTES,        \
+            GramCfg<WM, WN, TM, TN, BK, K3M>::THREADS, 1, GramCfg<WM, WN, TM, TN, BK, K3M>::LDS_BYTES,     \
             (const void*)gram_kernel<WM, WN, TM, TN, BK, K3M>, launch_variant<WM, WN, TM, TN, BK, K3M>     \
+    }
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool K3M>
+void launch_dma_variant(const GramArgs& args, unsigned blocks, hipStream_t stream) {
+    using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, K3M>;
+    hipLaunchKernelGGL((gram_dma_kernel<WAVES_M, WAVES_N, TM, TN, K3M>), dim3(blocks), dim3(C::THREADS), C::LDS_BYTES,
+                       stream, args);
+}
+
+#define QK_DMA_VARIANT(NAME, WM, WN, TM, TN, K3M)                                                          \
+    Variant {                                                                                              \
+        NAME, GramDmaCfg<WM, WN, TM, TN, K3M>::BM, GramDmaCfg<WM, WN, TM, TN, K3M>::BN,                    \
+            GramDmaCfg<WM, WN, TM, TN, K3M>::THREADS, 16, GramDmaCfg<WM, WN, TM, TN, K3M>::LDS_BYTES,      \
+            (const void*)gram_dma_kernel<WM, WN, TM, TN, K3M>, launch_dma_variant<WM, WN, TM, TN, K3M>     \
     }
 
 static const Variant kVariants[] = {
@@ -338,14 +565,15 @@ static const Variant kVariants[] = {
     QK_VARIANT("4m_128x128_w8_bk16", 2, 4, 4, 2, 16, false),
     QK_VARIANT("3m_96x128_w8_bk16", 2, 4, 3, 2, 16, true),
     QK_VARIANT("3m_128x96_w8_bk16", 4, 2, 2, 3, 16, true),
-    QK_VARIANT("3m_128x128_w4_bk8", 2, 2, 4, 4, 8, true),
-    QK_VARIANT("4m_128x128_w4_bk8", 2, 2, 4, 4, 8, false),
-    QK_VARIANT("4m_128x128_w4_bk16", 2, 2, 4, 4, 16, false),
+    QK_DMA_VARIANT("dma3m_128x128_w8", 2, 4, 4, 2, true),
+    QK_DMA_VARIANT("dma3m_96x128_w8", 2, 4, 3, 2, true),   // BM = 96: 24 rows per wave
+    QK_DMA_VARIANT("dma4m_128x128_w8", 2, 4, 4, 2, false),
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 2;  // 3m_96x128_w8_bk16: fastest measured (tools/gram_ab.py)
+constexpr int kDefaultVariant = 4;  // dma3m_128x128_w8: fastest measured (tools/gram_ab.py); variant 0 serves D < 16
 
 static int g_variant = -1;
+static int g_dbg = 0;
 static bool g_attr_set[kNumVariants] = {false};
 
 static int pick_variant() {
@@ -371,15 +599,20 @@ extern "C" int qk_gram_set_variant(const char* name) {
     return fail(QK_ERR_INVALID, "qk_gram_set_variant: unknown variant");
 }
 
+extern "C" int qk_gram_set_debug(int v) { qk::g_dbg = v; return 0; }
+
 extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
     using namespace qk;
     if (!jobs || n_jobs < 1 || n_jobs > QK_GRAM_MAX_JOBS)
         return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: need 1..16 jobs");
     if (D < 1 || (D & (D - 1)) != 0) return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: D must be a power of two");
-    const Variant& V = kVariants[pick_variant()];
+    int vi = pick_variant();
+    if (D < kVariants[vi].min_d) vi = 0;  // LDS-DMA tiles need 16 amplitudes per k-tile; tiny circuits use variant 0
+    const Variant& V = kVariants[vi];
     GramArgs args;
     std::memset(&args, 0, sizeof(args));
     args.D = D;
+    args.dbg = g_dbg;
     int64_t blocks = 0;
     int nj = 0;
     for (int k = 0; k < n_jobs; ++k) {
@@ -418,7 +651,6 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
     if (nj == 0) return QK_OK;
     args.n_jobs = nj;
     if (blocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, "qk_gram_jobs_dev: too many tiles; split the call");
-    const int vi = pick_variant();
     if (!g_attr_set[vi]) {
         QK_HIP(hipFuncSetAttribute(V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds));
         g_attr_set[vi] = true;
