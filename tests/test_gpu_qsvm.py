@@ -1,0 +1,81 @@
+"""Callers of kernel.evaluate (reference qsvm/train.py:30-166, genetic_v3.py:604-661) on the
+GPU path vs the same sklearn plumbing fed by the oracle: identical SVC predictions."""
+import numpy as np
+import pytest
+
+from oracle import qk_oracle as O
+from quake_amd import genetic, qsvm
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleKernel:
+    def __init__(self, ops, n):
+        self.ops, self.n = ops, n
+
+    def evaluate(self, x_vec, y_vec=None):
+        return O.evaluate(self.ops, self.n, x_vec, y_vec)
+
+
+def _toy(seed, n, F=2):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, F))
+    y = (X[:, 0] * X[:, 1] > 0).astype(float)       # XOR-like, needs a non-linear kernel
+    return X, y
+
+
+def test_train_and_evaluate_match_oracle(tmp_path):
+    feats, labs = zip(*[_toy(s, n) for s, n in ((1, 120), (2, 60), (3, 50))])
+    setup = {"model": {"qsvm": {"should_do_scaling": True, "split_ratio": 0.5, "should_add_extra_feats": False}}}
+    models, metrics = qsvm.qsvm_train_from_features(list(feats), list(labs), tmp_path, setup)
+    assert (tmp_path / "c2.sav").exists() and (tmp_path / "gen1.sav").exists() and (tmp_path / "gen2.sav").exists()
+    # same flow with oracle kernels
+    from sklearn.model_selection import train_test_split
+    ds = qsvm.rearrange_scale(*feats, True)
+    lb = list(labs)
+    ds[0], lb[0] = train_test_split(ds[0], lb[0], train_size=0.5, random_state=42)[::2]
+    oks = [OracleKernel(O.custom2_featuremap(2, 1), 2), OracleKernel(O.genetic_featuremap(1), 2),
+           OracleKernel(O.genetic_featuremap_2(1), 2)]
+    omodels = qsvm.qsvm_hyperparameter_training(None, ds, lb, oks, ["c2", "gen1", "gen2"])
+    ometrics = qsvm.evaluate_svm(omodels, ds, lb, oks)
+    for key in ("accuracy", "sensitivity", "specificity"):
+        assert np.array_equal(metrics[key], ometrics[key]), key
+    # AUC goes through predict_proba: Platt scaling with an unseeded internal 5-fold split (the
+    # reference passes no random_state), so it moves in the 4th digit from fit to fit
+    assert np.abs(metrics["auc"] - ometrics["auc"]).max() < 2e-2
+    assert metrics["accuracy"].shape == (3, 3) and metrics["accuracy"][:, 0].min() > 0.5
+    # the intended model (kernel="precomputed" on the final refit) also runs
+    kernels, titles = qsvm.load_quantum_kernels(2)
+    m2 = qsvm.qsvm_hyperparameter_training(None, ds, lb, kernels, titles, final_kernel="precomputed")
+    assert m2[0].kernel == "precomputed" and models[0].kernel == "rbf"
+
+
+def test_runcard_feature_maps(tmp_path):
+    card = tmp_path / "runcard.yaml"
+    card.write_text("output: !Path out\nmodel:\n  qsvm:\n    should_do_scaling: true\n    split_ratio: 0.6\n"
+                    "    feature_maps: [[zz, {repeats: 2}], [z, {}]]\n")
+    setup = qsvm.load_runcard(card)
+    assert str(setup["output"]) == "out"
+    feats, labs = zip(*[_toy(s, n, F=4) for s, n in ((4, 80), (5, 40), (6, 30))])
+    models, metrics = qsvm.qsvm_train_from_features(list(feats), list(labs), None, setup)
+    assert len(models) == 2 and np.isfinite(metrics["auc"]).all()
+
+
+def test_genetic_fitness_matches_oracle(pins, data8, data_labels):
+    from sklearn.model_selection import cross_val_score
+    from sklearn.svm import SVC
+    p = pins["P2"]
+    fit = lambda accuracy, density, depth: accuracy + 0.05 * density   # examples/torino_run.py:96-98
+    val, stats = genetic.fitness(p["genes"], data8, data_labels, p["gate_dict"], 8, 8, 4, fit)
+    ops, xi = O.to_quantum(p["genes"], p["gate_dict"], 8, 8, 4)
+    K = O.evaluate(ops, 4, data8[:, xi])
+    acc = cross_val_score(SVC(kernel="precomputed"), K, data_labels, cv=4, scoring="accuracy").mean()
+    ref = genetic.kernel_statistics(K, data_labels)
+    assert stats["accuracy"] == acc
+    for k in ("sparsity", "offdiagonal_mean", "offdiagonal_std"):
+        assert abs(stats[k] - ref[k]) < 1e-13
+    assert abs(val - (acc + 0.05 * ref["offdiagonal_std"])) < 1e-13
+    # projected variant runs through the same entry point
+    v2, s2 = genetic.fitness(p["genes"], data8, data_labels, p["gate_dict"], 8, 8, 4, fit, projected=True)
+    Kp = O.projected_kernel(ops, 4, data8[:, xi], 1)
+    assert abs(s2["offdiagonal_std"] - np.std(np.triu(Kp, 1))) < 1e-13
