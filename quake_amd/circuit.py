@@ -42,7 +42,7 @@ PARAMETRIC = {"rx", "ry", "rz", "p"}
 TWO_QUBIT = {"cx", "cz", "ecr"}
 
 (EX_CONST, EX_PARAM, EX_ADD, EX_SUB, EX_MUL, EX_DIV, EX_NEG, EX_ASIN, EX_ACOS, EX_SIN, EX_COS) = range(11)
-MAX_EXPR_STACK = 16
+MAX_EXPR_STACK = 8
 
 
 # --------------------------------------------------------------------------- #

@@ -95,7 +95,7 @@ extern "C" int qk_circuit_create(int n_qubits, int n_params, const qk_op* ops, i
                 default:
                     return fail(QK_ERR_INVALID, "angle program: unknown opcode");
             }
-            if (depth > 16) return fail(QK_ERR_INVALID, "angle program: deeper than 16 stack slots");
+            if (depth > 8) return fail(QK_ERR_INVALID, "angle program: deeper than 8 stack slots");
         }
         if (depth != 1) return fail(QK_ERR_INVALID, "angle program: does not leave exactly one value");
     }

@@ -88,6 +88,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     for (const Item& it : items) {
         if (it.diag) {
             pending.push_back(it);
+            if ((int)pending.size() >= kMaxTermPerPass - 64) flush();  // a stage's terms must fit one pass
             continue;
         }
         // qubits on which this gate is NOT diagonal (a cx is diagonal on its control)
@@ -107,7 +108,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     // ---- 3. passes --------------------------------------------------------
     const int Lmax = std::min(n, kMaxLocalQubits);
     const int n_fixed = (n > Lmax) ? std::min(4, n) : 0;  // low qubits kept local: 256-B runs in HBM
-    struct Draft { std::vector<int> S; std::vector<int> stage_ids; int n_expr = 0, n_mat = 0; };
+    struct Draft { std::vector<int> S; std::vector<int> stage_ids; int n_term = 0, n_mat = 0; };
     std::vector<Draft> drafts;
     auto new_draft = [&]() {
         Draft d;
@@ -122,27 +123,25 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     for (int s = 0; s < (int)seq.size(); ++s) {
         const Proto& p = seq[s];
         std::vector<int> need;
-        int add_expr = 0, add_mat = 0;
+        int add_term = 0, add_mat = 0;
         if (p.diag) {
-            for (const Item& t : p.terms) add_expr += (t.expr >= 0);
+            add_term = (int)p.terms.size();
         } else {
-            if (p.nd.kind == ST_U1) { need = {p.nd.q0}; add_mat = 1; add_expr = (p.nd.expr >= 0); }
+            if (p.nd.kind == ST_U1) { need = {p.nd.q0}; add_mat = 1; }
             if (p.nd.kind == ST_CX) need = {p.nd.q1};
             if (p.nd.kind == ST_ECR) need = {p.nd.q0, p.nd.q1};
         }
-        if (add_expr > kMaxExprPerPass)
-            return fail(QK_ERR_UNSUPPORTED, "too many parametric diagonal gates in one run");
         for (int attempt = 0; attempt < 2; ++attempt) {
             Draft& d = drafts.back();
             std::vector<int> S2 = d.S;
             for (int q : need)
                 if (std::find(S2.begin(), S2.end(), q) == S2.end()) S2.push_back(q);
-            const bool fits = (int)S2.size() <= Lmax && d.n_expr + add_expr <= kMaxExprPerPass &&
+            const bool fits = (int)S2.size() <= Lmax && d.n_term + add_term <= kMaxTermPerPass &&
                               d.n_mat + add_mat <= kMaxMatPerPass;
             if (fits) {
                 d.S = S2;
                 d.stage_ids.push_back(s);
-                d.n_expr += add_expr;
+                d.n_term += add_term;
                 d.n_mat += add_mat;
                 break;
             }
@@ -152,6 +151,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     }
 
     c.passes.clear();
+    uint32_t active = 0;  // qubits a non-diagonal gate has acted on so far
     c.stages.clear();
     c.terms.clear();
     c.exprs.clear();
@@ -165,7 +165,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         Pass ps;
         ps.L = Lmax;
         ps.first = (pi == 0);
-        ps.lgT = ps.L >= 11 ? 10 : std::max(6, ps.L - 1);
+        ps.lgT = ps.L >= 12 ? 9 : (ps.L >= 9 ? 8 : std::max(6, ps.L - 1));
+        ps.h = ps.L <= 8 ? ps.L : (ps.L + 1) / 2;
+        ps.maxg = ps.L >= 12 ? 3 : 2;   // radix-8 sweeps need the 512-thread / 256-VGPR kernel
         ps.phys = d.S;
         for (int q = 0; q < n; ++q)
             if (std::find(d.S.begin(), d.S.end(), q) == d.S.end()) ps.phys.push_back(q);
@@ -186,49 +188,95 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         ps.stage_off = (int)c.stages.size();
         ps.expr_off = (int)c.exprs.size();
         ps.mat_off = (int)c.mats.size();
-        const int lgT_eff = std::min(ps.lgT, ps.L);
-        auto add_expr = [&](int e, double scale) -> int {
-            c.exprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale});
-            return (int)c.exprs.size() - 1 - ps.expr_off;
+        ps.term_off = (int)c.terms.size();
+        auto add_expr = [&](int e, double scale, int dst) {
+            c.exprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale, dst, 0});
         };
+        auto mask_of = [&](uint32_t qubit_mask) {
+            uint32_t m = 0;
+            for (int q = 0; q < n; ++q)
+                if (qubit_mask >> q & 1u) m |= 1u << virt[q];
+            return m;
+        };
+        ps.zero_in = mask_of(~active & ((n >= 32) ? 0xffffffffu : ((1u << n) - 1u)));
         for (int s : d.stage_ids) {
             const Proto& p = seq[s];
             DevStage st{};
             if (p.diag) {
                 st.kind = ST_DIAG;
-                st.t0 = (int)c.terms.size();
-                std::vector<DevTerm> A, B;
+                st.t0 = (int)c.terms.size() - ps.term_off;
+                std::vector<std::pair<DevTerm, int>> lo, hi, cross;   // (term, global expr or -1)
                 for (const Item& t : p.terms) {
                     DevTerm dt{};
                     dt.type = t.kind;
                     dt.va = virt[t.q0];
                     dt.vb = t.q1 >= 0 ? virt[t.q1] : 0;
-                    dt.cs = t.expr >= 0 ? add_expr(t.expr, t.kind == TM_RZ ? 0.5 : 1.0) : -1;
-                    auto thread_const = [&](int v) { return v < lgT_eff || v >= ps.L; };
-                    const bool isA = thread_const(dt.va) && (t.q1 < 0 || thread_const(dt.vb));
-                    (isA ? A : B).push_back(dt);
+                    bool in_lo = false, in_hi = false;
+                    auto look = [&](int v) { if (v < ps.h) in_lo = true; else if (v < ps.L) in_hi = true; };
+                    look(dt.va);
+                    if (t.q1 >= 0) look(dt.vb);
+                    (in_lo && in_hi ? cross : (in_hi ? hi : lo)).push_back({dt, t.expr});
                 }
-                st.nA = (int)A.size();
-                st.nB = (int)B.size();
-                c.terms.insert(c.terms.end(), A.begin(), A.end());
-                c.terms.insert(c.terms.end(), B.begin(), B.end());
-            } else {
-                const Item& g = p.nd;
-                st.kind = g.kind;
-                if (g.kind == ST_U1) {
-                    st.va = virt[g.q0];
-                    DevMat m{g.gate, g.expr >= 0 ? add_expr(g.expr, 0.5) : -1};
-                    c.mats.push_back(m);
-                    st.idx = (int)c.mats.size() - 1 - ps.mat_off;
-                } else {
-                    st.va = virt[g.q0];
-                    st.vb = virt[g.q1];
-                }
+                st.nLo = (int)lo.size();
+                st.nHi = (int)hi.size();
+                st.nX = (int)cross.size();
+                for (auto* grp : {&lo, &hi, &cross})
+                    for (auto& te : *grp) {
+                        c.terms.push_back(te.first);
+                        if (te.second >= 0)
+                            add_expr(te.second, te.first.type == TM_RZ ? 0.5 : 1.0, (int)c.terms.size() - 1 - ps.term_off);
+                    }
+                c.stages.push_back(st);
+                continue;
             }
-            c.stages.push_back(st);
+            const Item& g = p.nd;
+            if (g.kind == ST_U1) {
+                active |= 1u << g.q0;
+                c.mats.push_back(DevMat{g.gate, 0});
+                const int mi = (int)c.mats.size() - 1 - ps.mat_off;
+                if (g.expr >= 0) add_expr(g.expr, 0.5, ~mi);
+                const int v = virt[g.q0];
+                // fuse with the previous stage if that is a U1 group in this pass without this qubit
+                bool fused = false;
+                if ((int)c.stages.size() > ps.stage_off) {
+                    DevStage& prev = c.stages.back();
+                    if (prev.kind == ST_U1 && prev.ng < ps.maxg) {
+                        bool clash = false;
+                        for (int k = 0; k < prev.ng; ++k) clash |= (prev.gv[k] == v);
+                        if (!clash) {
+                            int k = prev.ng++;
+                            prev.gv[k] = v;
+                            prev.gm[k] = mi;
+                            // keep target bits ascending (the gates act on different qubits: they commute)
+                            for (; k > 0 && prev.gv[k - 1] > prev.gv[k]; --k) {
+                                std::swap(prev.gv[k - 1], prev.gv[k]);
+                                std::swap(prev.gm[k - 1], prev.gm[k]);
+                            }
+                            fused = true;
+                        }
+                    }
+                }
+                if (!fused) {
+                    st.kind = ST_U1;
+                    st.ng = 1;
+                    st.gv[0] = v;
+                    st.gm[0] = mi;
+                    c.stages.push_back(st);
+                }
+            } else {
+                st.kind = g.kind;
+                st.va = virt[g.q0];
+                st.vb = virt[g.q1];
+                active |= 1u << g.q1;                       // cx target / ecr second qubit
+                if (g.kind == ST_ECR) active |= 1u << g.q0;
+                c.stages.push_back(st);
+            }
         }
+        if (pi + 1 < drafts.size())
+            ps.zero_out = mask_of(~active & ((n >= 32) ? 0xffffffffu : ((1u << n) - 1u)));
         ps.n_stage = (int)c.stages.size() - ps.stage_off;
         ps.n_expr = (int)c.exprs.size() - ps.expr_off;
+        ps.n_term = (int)c.terms.size() - ps.term_off;
         ps.n_mat = (int)c.mats.size() - ps.mat_off;
         c.passes.push_back(ps);
     }

@@ -29,46 +29,58 @@ int fail(int code, const std::string& msg);
 // 0..L-1 (ascending qubit order), chunk qubits take L..n-1.
 
 enum StageKind : int32_t { ST_DIAG = 0, ST_U1 = 1, ST_CX = 2, ST_ECR = 3 };
+constexpr int kMaxGroup = 3;  // single-qubit gates on distinct qubits fused into one radix-8 sweep
 enum TermKind : int32_t { TM_P = 0, TM_RZ = 1, TM_CZ = 2, TM_ZZP = 3 };
 
-struct DevTerm {      // one factor of a diagonal stage
+struct DevTerm {      // one factor of a diagonal stage (device table)
     int32_t type;     // TermKind
     int32_t va, vb;   // virtual bit positions (vb unused for TM_P / TM_RZ)
-    int32_t cs;       // pass-local index of the (cos, sin) pair, -1 for TM_CZ
+    int32_t pad;
 };
 
 struct DevStage {
     int32_t kind;     // StageKind
-    int32_t va, vb;   // U1: va = target; CX: va = control, vb = target; ECR: va = q0, vb = q1
-    int32_t idx;      // U1: pass-local matrix index
-    int32_t t0;       // DIAG: first term
-    int32_t nA;       // DIAG: terms constant per thread (bits < lgT or chunk bits)
-    int32_t nB;       // DIAG: terms evaluated per amplitude
-    int32_t pad;
+    int32_t va, vb;   // CX: va = control, vb = target; ECR: va = q0, vb = q1
+    int32_t ng;       // U1: number of fused gates (1..kMaxGroup), on distinct local qubits
+    int32_t gv[kMaxGroup];  // U1: target bits, ascending
+    int32_t gm[kMaxGroup];  // U1: pass-local matrix index of the gate on gv[k]
+    // DIAG: pass-local terms [t0, t0+nLo) depend on local bits < h only (plus chunk bits),
+    // the next nHi on local bits >= h only, the last nX on both halves
+    int32_t t0, nLo, nHi, nX;
 };
 
 struct DevExpr {      // one gate angle evaluated per sample
     int32_t start, len;   // slice of the postfix program
     double scale;         // 0.5 for rx/ry/rz (half angle), 1 for p
+    int32_t dst;          // >= 0: pass-local term that takes (cos, sin); < 0: matrix ~dst
+    int32_t pad;
 };
 
-struct DevMat {       // how to fill a 2x2 matrix from the gate kind and its (cos, sin)
-    int32_t gate;     // qk_gate (H, X, SX, RX, RY)
-    int32_t cs;       // pass-local (cos, sin) index or -1
+struct DevMat {       // a 2x2 matrix: constant for h / x / sx, filled from its angle for rx / ry
+    int32_t gate;     // qk_gate
+    int32_t pad;
 };
 
 constexpr int kMaxRuns = 16;
 constexpr int kMaxLocalQubits = 13;          // 2^13 * 16 B = 128 KiB of LDS
-constexpr int kMaxExprPerPass = 640;         // 10 KiB of (cos, sin)
-constexpr int kMaxMatPerPass = 288;          // 18 KiB of 2x2 complex matrices
+constexpr int kMaxTermPerPass = 256;         // 8 KiB of resolved diagonal terms in LDS
+constexpr int kMaxMatPerPass = 160;          // 10 KiB of 2x2 complex matrices
 
 struct Pass {
     int L = 0;                 // local qubits
     int lgT = 6;               // log2(threads)
+    int h = 0;                 // diagonal stages: local bits < h index the low phase table, the rest the high one
+    int maxg = 2;              // largest fused single-qubit group (3 needs the 256-VGPR kernel)
     bool first = false;        // starts from |0...0> (no load)
+    // Qubits no non-diagonal gate has touched yet are still |0>: every amplitude with such a bit
+    // set is exactly zero.  zero_in: those bits (virtual positions) when the pass starts -- not
+    // loaded; zero_out: those still untouched after a pass that is not the last -- not stored
+    // (the next pass knows they are zero).
+    uint32_t zero_in = 0, zero_out = 0;
     std::vector<int> phys;     // phys[v] = physical qubit at virtual position v (size n)
     int stage_off = 0, n_stage = 0;
     int expr_off = 0, n_expr = 0;
+    int term_off = 0, n_term = 0;
     int mat_off = 0, n_mat = 0;
     // bit-deposit runs: physical = OR_r ((virtual & mask[r]) << shift[r])
     int nruns = 0;

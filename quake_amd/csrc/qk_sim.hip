@@ -11,7 +11,9 @@
 // Psi is written to HBM in 16-byte elements, consecutive lanes -> consecutive amplitudes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "qk_common.h"
 
@@ -28,11 +30,21 @@ struct SimArgs {
     const DevMat* mats;
     const qk_instr* prog;
     const double* consts;
-    int n_stage, n_expr, n_mat;
-    int L, lgT, n_qubits, first;
+    int n_stage, n_expr, n_mat, n_term;
+    int L, h, n_qubits, first;
+    uint32_t zero_in, zero_out;  // virtual-bit masks of still-|0> qubits (see Pass)
+    uint32_t live_chunks;        // chunk-index bits that are not known-zero after the pass
+    int nlive;                   // popcount(live_chunks)
+    int64_t n_items;             // N << nlive (sample, live chunk) pairs
     int nruns;
     uint32_t run_mask[kMaxRuns];
     int32_t run_shift[kMaxRuns];
+};
+
+// a diagonal term with its per-sample (cos, sin) resolved, 32 bytes in LDS
+struct RTerm {
+    double c, s;
+    int32_t type, va, vb, pad;
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -52,189 +64,257 @@ __device__ __forceinline__ uint32_t deposit(uint32_t w, const SimArgs& a) {
     return g;
 }
 
-// factor of one diagonal term for the amplitude whose virtual index is w
-__device__ __forceinline__ void apply_term(const DevTerm& t, uint32_t w, const double2* cs, double& fr, double& fi) {
-    const uint32_t ba = (w >> t.va) & 1u;
-    if (t.type == TM_CZ) {
-        const uint32_t bb = (w >> t.vb) & 1u;
-        if (ba & bb) { fr = -fr; fi = -fi; }
-        return;
-    }
-    const double2 c = cs[t.cs];
-    double s;
-    bool on = true;
-    if (t.type == TM_RZ) {
-        s = ba ? c.y : -c.y;       // diag(e^{-i th/2}, e^{+i th/2})
-    } else if (t.type == TM_P) {
-        on = ba;                   // diag(1, e^{i lam})
-        s = c.y;
-    } else {                       // TM_ZZP: e^{i lam} where the two bits differ
-        const uint32_t bb = (w >> t.vb) & 1u;
-        on = (ba ^ bb);
-        s = c.y;
+// multiply f by the factor of one diagonal term for the amplitude with virtual index w
+__device__ __forceinline__ void apply_term(const RTerm& t, uint32_t w, double& fr, double& fi) {
+    const uint32_t ba = (w >> t.va) & 1u, bb = (w >> t.vb) & 1u;
+    double s = t.s;
+    bool on;
+    if (t.type == TM_RZ) {            // diag(e^{-i th/2}, e^{+i th/2})
+        on = true;
+        s = ba ? s : -s;
+    } else if (t.type == TM_P) {      // diag(1, e^{i lam})
+        on = ba;
+    } else if (t.type == TM_CZ) {     // (c, s) = (-1, 0) where both bits are set
+        on = ba & bb;
+    } else {                          // TM_ZZP: e^{i lam} where the two bits differ
+        on = ba ^ bb;
     }
     if (on) {
-        const double nr = fma(fr, c.x, -(fi * s));
-        const double ni = fma(fr, s, fi * c.x);
+        const double nr = fma(fr, t.c, -(fi * s));
+        const double ni = fma(fr, s, fi * t.c);
         fr = nr;
         fi = ni;
     }
 }
 
-__global__ void __launch_bounds__(1024) sim_pass_kernel(SimArgs a) {
+template <int NG>
+__device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, const DevStage& st, uint32_t nloc,
+                                         int tid, int T) {
+    // NG single-qubit gates on distinct local qubits in one sweep: each thread holds the 2^NG
+    // amplitudes that differ in the target bits and applies the gates in registers
+    double2 m[NG][4];
+    uint32_t lm[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[g][k] = mat[4 * st.gm[g] + k];
+        lm[g] = (1u << st.gv[g]) - 1u;
+    }
+    for (uint32_t i = tid; i < (nloc >> NG); i += T) {
+        uint32_t b = i;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) b = ((b & ~lm[g]) << 1) | (b & lm[g]);   // target bits ascending
+        double2 v[1 << NG];
+        uint32_t idx[1 << NG];
+#pragma unroll
+        for (int k = 0; k < (1 << NG); ++k) {
+            uint32_t o = b;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) o |= ((k >> g) & 1u) << st.gv[g];
+            idx[k] = o;
+            v[k] = state[o];
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int k = 0; k < (1 << NG); ++k)
+                if (!((k >> g) & 1)) {
+                    const int k1 = k | (1 << g);
+                    const double2 a0 = v[k], a1 = v[k1];
+                    v[k] = cfma(m[g][1], a1, cmul(m[g][0], a0));
+                    v[k1] = cfma(m[g][3], a1, cmul(m[g][2], a0));
+                }
+#pragma unroll
+        for (int k = 0; k < (1 << NG); ++k) state[idx[k]] = v[k];
+    }
+}
+
+// MAXG = 3: 512 threads, up to 256 VGPRs (radix-8 sweeps); MAXG = 2: 256 threads, up to 168 VGPRs, 3 waves/SIMD
+template <int MAXG>
+__global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, MAXG == 3 ? 2 : 3) sim_pass_kernel(SimArgs a) {
     extern __shared__ double2 lds[];
-    const int L = a.L;
+    const int L = a.L, h = a.h;
     const uint32_t nloc = 1u << L;
     double2* state = lds;
-    double2* cs = lds + nloc;                                   // n_expr (cos, sin) pairs
-    double2* mat = cs + a.n_expr;                               // n_mat * 4 complex entries
+    RTerm* rt = (RTerm*)(lds + nloc);                       // n_term resolved diagonal terms
+    double2* mat = (double2*)(rt + a.n_term);               // n_mat * 4 complex entries
+    double2* tlo = mat + 4 * a.n_mat;                       // phase table over local bits < h
+    double2* thi = tlo + (1u << h);                         // phase table over local bits >= h
     const int tid = threadIdx.x;
     const int T = blockDim.x;
-    const int nchunk_bits = a.n_qubits - L;
-    const uint32_t chunk = blockIdx.x & ((1u << nchunk_bits) - 1u);
-    const int64_t sample = blockIdx.x >> nchunk_bits;
-    const double* xrow = a.X + sample * a.ldx;
-
-    // ---- per-sample gate angles -> (cos, sin) ------------------------------
-    for (int e = tid; e < a.n_expr; e += T) {
-        const DevExpr ex = a.exprs[e];
-        double st[16];
-        int sp = 0;
-        for (int k = 0; k < ex.len; ++k) {
-            const qk_instr in = a.prog[ex.start + k];
-            switch (in.op) {
-                case QK_EX_CONST: st[sp++] = a.consts[in.arg]; break;
-                case QK_EX_PARAM: st[sp++] = xrow[in.arg]; break;
-                case QK_EX_ADD: --sp; st[sp - 1] = st[sp - 1] + st[sp]; break;
-                case QK_EX_SUB: --sp; st[sp - 1] = st[sp - 1] - st[sp]; break;
-                case QK_EX_MUL: --sp; st[sp - 1] = st[sp - 1] * st[sp]; break;
-                case QK_EX_DIV: --sp; st[sp - 1] = st[sp - 1] / st[sp]; break;
-                case QK_EX_NEG: st[sp - 1] = -st[sp - 1]; break;
-                case QK_EX_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
-                case QK_EX_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
-                case QK_EX_SIN: st[sp - 1] = sin(st[sp - 1]); break;
-                case QK_EX_COS: st[sp - 1] = cos(st[sp - 1]); break;
-                default: break;
-            }
+    // Persistent workgroups: each walks (sample, chunk) items with a grid stride, so the launch cost
+    // is paid once per CU slot.  Chunks whose amplitudes are all still zero after the pass (and a
+    // later pass knows) are not items at all.
+    for (int64_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        uint32_t chunk = 0;
+        {
+            uint32_t ci = (uint32_t)(item & ((1u << a.nlive) - 1u)), m = a.live_chunks;
+            for (int b = 0; m; ++b, m >>= 1)
+                if (m & 1u) { chunk |= (ci & 1u) << b; ci >>= 1; }
         }
-        const double ang = st[0] * ex.scale;
-        double sn, cn;
-        sincos(ang, &sn, &cn);
-        cs[e] = make_double2(cn, sn);
-    }
-    // ---- initial state / chunk load ----------------------------------------
-    const uint32_t chunk_phys = deposit(chunk << L, a);
-    double2* gpsi = a.psi + sample * a.D;
-    if (a.first) {
-        for (uint32_t l = tid; l < nloc; l += T) state[l] = make_double2(0.0, 0.0);
-    } else {
-        for (uint32_t l = tid; l < nloc; l += T) state[l] = gpsi[chunk_phys | deposit(l, a)];
-    }
-    __syncthreads();
-    if (a.first && chunk == 0 && tid == 0) state[0] = make_double2(1.0, 0.0);
-    // ---- 2x2 matrices -------------------------------------------------------
-    for (int m = tid; m < a.n_mat; m += T) {
-        const DevMat dm = a.mats[m];
-        double2 m00, m01, m10, m11;
-        const double r = 0.70710678118654752440;
-        if (dm.gate == QK_H) {
-            m00 = make_double2(r, 0); m01 = make_double2(r, 0); m10 = make_double2(r, 0); m11 = make_double2(-r, 0);
-        } else if (dm.gate == QK_X) {
-            m00 = make_double2(0, 0); m01 = make_double2(1, 0); m10 = make_double2(1, 0); m11 = make_double2(0, 0);
-        } else if (dm.gate == QK_SX) {
-            m00 = make_double2(0.5, 0.5); m01 = make_double2(0.5, -0.5);
-            m10 = make_double2(0.5, -0.5); m11 = make_double2(0.5, 0.5);
+        const int64_t sample = item >> a.nlive;
+        const double* xrow = a.X + sample * a.ldx;
+        const uint32_t whi = chunk << L;
+
+        // ---- static parts of the tables: term kinds/bits, constant matrices ----------
+        for (int t = tid; t < a.n_term; t += T) {
+            const DevTerm d = a.terms[t];
+            RTerm r;
+            r.c = -1.0; r.s = 0.0;            // TM_CZ; parametric terms get their (cos, sin) below
+            r.type = d.type; r.va = d.va; r.vb = d.vb; r.pad = 0;
+            rt[t] = r;
+        }
+        for (int m = tid; m < a.n_mat; m += T) {
+            const int gate = a.mats[m].gate;
+            const double r = 0.70710678118654752440;
+            double2 m00 = make_double2(0, 0), m01 = m00, m10 = m00, m11 = m00;
+            if (gate == QK_H) {
+                m00 = make_double2(r, 0); m01 = make_double2(r, 0); m10 = make_double2(r, 0); m11 = make_double2(-r, 0);
+            } else if (gate == QK_X) {
+                m01 = make_double2(1, 0); m10 = make_double2(1, 0);
+            } else if (gate == QK_SX) {
+                m00 = make_double2(0.5, 0.5); m01 = make_double2(0.5, -0.5);
+                m10 = make_double2(0.5, -0.5); m11 = make_double2(0.5, 0.5);
+            }
+            mat[4 * m + 0] = m00; mat[4 * m + 1] = m01; mat[4 * m + 2] = m10; mat[4 * m + 3] = m11;
+        }
+        // ---- initial state / chunk load -------------------------------------------------
+        // amplitudes with a bit of a still-|0> qubit set are zero by construction: never loaded
+        const uint32_t chunk_phys = deposit(whi, a);
+        double2* gpsi = a.psi + sample * a.D;
+        if (a.first || (whi & a.zero_in)) {
+            for (uint32_t l = tid; l < nloc; l += T) state[l] = make_double2(0.0, 0.0);
         } else {
-            const double2 c = cs[dm.cs];  // cos, sin of theta/2
-            if (dm.gate == QK_RX) {
-                m00 = make_double2(c.x, 0); m01 = make_double2(0, -c.y);
-                m10 = make_double2(0, -c.y); m11 = make_double2(c.x, 0);
-            } else {  // QK_RY
-                m00 = make_double2(c.x, 0); m01 = make_double2(-c.y, 0);
-                m10 = make_double2(c.y, 0); m11 = make_double2(c.x, 0);
+            for (uint32_t l = tid; l < nloc; l += T)
+                state[l] = (l & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | deposit(l, a)];
+        }
+        __syncthreads();
+        if (a.first && chunk == 0 && tid == 0) state[0] = make_double2(1.0, 0.0);
+        // ---- per-sample gate angles -> (cos, sin) into their term or matrix ---------------
+        for (int e = tid; e < a.n_expr; e += T) {
+            const DevExpr ex = a.exprs[e];
+            double st[8];
+            int sp = 0;
+            for (int k = 0; k < ex.len; ++k) {
+                const qk_instr in = a.prog[ex.start + k];
+                switch (in.op) {
+                    case QK_EX_CONST: st[sp++] = a.consts[in.arg]; break;
+                    case QK_EX_PARAM: st[sp++] = xrow[in.arg]; break;
+                    case QK_EX_ADD: --sp; st[sp - 1] = st[sp - 1] + st[sp]; break;
+                    case QK_EX_SUB: --sp; st[sp - 1] = st[sp - 1] - st[sp]; break;
+                    case QK_EX_MUL: --sp; st[sp - 1] = st[sp - 1] * st[sp]; break;
+                    case QK_EX_DIV: --sp; st[sp - 1] = st[sp - 1] / st[sp]; break;
+                    case QK_EX_NEG: st[sp - 1] = -st[sp - 1]; break;
+                    case QK_EX_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
+                    case QK_EX_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
+                    case QK_EX_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+                    case QK_EX_COS: st[sp - 1] = cos(st[sp - 1]); break;
+                    default: break;
+                }
+            }
+            double sn, cn;
+            sincos(st[0] * ex.scale, &sn, &cn);
+            if (ex.dst >= 0) {
+                rt[ex.dst].c = cn;
+                rt[ex.dst].s = sn;
+            } else {  // rx / ry from cos, sin of theta/2
+                const int m = ~ex.dst;
+                if (a.mats[m].gate == QK_RX) {
+                    mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(0, -sn);
+                    mat[4 * m + 2] = make_double2(0, -sn); mat[4 * m + 3] = make_double2(cn, 0);
+                } else {
+                    mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(-sn, 0);
+                    mat[4 * m + 2] = make_double2(sn, 0); mat[4 * m + 3] = make_double2(cn, 0);
+                }
             }
         }
-        mat[4 * m + 0] = m00; mat[4 * m + 1] = m01; mat[4 * m + 2] = m10; mat[4 * m + 3] = m11;
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- stages ---------------------------------------------------------------
-    const uint32_t whi = chunk << L;
-    for (int s = 0; s < a.n_stage; ++s) {
-        const DevStage st = a.stages[s];
-        if (st.kind == ST_DIAG) {
-            double zr = 1.0, zi = 0.0;
-            const DevTerm* tA = a.terms + st.t0;
-            const DevTerm* tB = tA + st.nA;
-            const uint32_t w0 = whi | (uint32_t)tid;
-            for (int k = 0; k < st.nA; ++k) apply_term(tA[k], w0, cs, zr, zi);
-            for (uint32_t l = tid; l < nloc; l += T) {
-                double fr = zr, fi = zi;
-                const uint32_t w = whi | l;
-                for (int k = 0; k < st.nB; ++k) apply_term(tB[k], w, cs, fr, fi);
-                const double2 v = state[l];
-                state[l] = make_double2(fma(v.x, fr, -(v.y * fi)), fma(v.x, fi, v.y * fr));
-            }
-        } else if (st.kind == ST_U1) {
-            const int p = st.va;
-            const double2 m00 = mat[4 * st.idx + 0], m01 = mat[4 * st.idx + 1];
-            const double2 m10 = mat[4 * st.idx + 2], m11 = mat[4 * st.idx + 3];
-            const uint32_t lowmask = (1u << p) - 1u;
-            for (uint32_t i = tid; i < (nloc >> 1); i += T) {
-                const uint32_t i0 = ((i & ~lowmask) << 1) | (i & lowmask);
-                const uint32_t i1 = i0 | (1u << p);
-                const double2 a0 = state[i0], a1 = state[i1];
-                state[i0] = cfma(m01, a1, cmul(m00, a0));
-                state[i1] = cfma(m11, a1, cmul(m10, a0));
-            }
-        } else if (st.kind == ST_CX) {
-            const int vc = st.va, vt = st.vb;
-            if (vc >= L) {  // control is a chunk bit: X on the target, or nothing
-                if ((whi >> vc) & 1u) {
-                    const uint32_t lowmask = (1u << vt) - 1u;
-                    for (uint32_t i = tid; i < (nloc >> 1); i += T) {
-                        const uint32_t i0 = ((i & ~lowmask) << 1) | (i & lowmask);
+        // ---- stages -----------------------------------------------------------------------
+        for (int s = 0; s < a.n_stage; ++s) {
+            const DevStage st = a.stages[s];
+            if (st.kind == ST_DIAG) {
+                // phase(w) = tlo[low h bits] * thi[high local bits] * (terms that straddle the halves);
+                // the two tables cost 2^h + 2^(L-h) term products instead of 2^L
+                const RTerm* tl = rt + st.t0;
+                const RTerm* th = tl + st.nLo;
+                const RTerm* tx = th + st.nHi;
+                const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
+                for (uint32_t j = tid; j < nlo + nhi; j += T) {
+                    double fr = 1.0, fi = 0.0;
+                    if (j < nlo) {
+                        const uint32_t w = whi | j;
+                        for (int k = 0; k < st.nLo; ++k) apply_term(tl[k], w, fr, fi);
+                        tlo[j] = make_double2(fr, fi);
+                    } else {
+                        const uint32_t w = whi | ((j - nlo) << h);
+                        for (int k = 0; k < st.nHi; ++k) apply_term(th[k], w, fr, fi);
+                        thi[j - nlo] = make_double2(fr, fi);
+                    }
+                }
+                __syncthreads();
+                for (uint32_t l = tid; l < nloc; l += T) {
+                    const double2 f0 = tlo[l & (nlo - 1u)], f1 = thi[l >> h];
+                    double fr = fma(f0.x, f1.x, -(f0.y * f1.y)), fi = fma(f0.x, f1.y, f0.y * f1.x);
+                    const uint32_t w = whi | l;
+                    for (int k = 0; k < st.nX; ++k) apply_term(tx[k], w, fr, fi);
+                    const double2 v = state[l];
+                    state[l] = make_double2(fma(v.x, fr, -(v.y * fi)), fma(v.x, fi, v.y * fr));
+                }
+            } else if (st.kind == ST_U1) {
+                if (st.ng == 1) sweep_u1<1>(state, mat, st, nloc, tid, T);
+                else if (st.ng == 2) sweep_u1<2>(state, mat, st, nloc, tid, T);
+                else if constexpr (MAXG >= 3) sweep_u1<3>(state, mat, st, nloc, tid, T);
+            } else if (st.kind == ST_CX) {
+                const int vc = st.va, vt = st.vb;
+                if (vc >= L) {  // control is a chunk bit: X on the target, or nothing
+                    if ((whi >> vc) & 1u) {
+                        const uint32_t lowmask = (1u << vt) - 1u;
+                        for (uint32_t i = tid; i < (nloc >> 1); i += T) {
+                            const uint32_t i0 = ((i & ~lowmask) << 1) | (i & lowmask);
+                            const uint32_t i1 = i0 | (1u << vt);
+                            const double2 a0 = state[i0];
+                            state[i0] = state[i1];
+                            state[i1] = a0;
+                        }
+                    }
+                } else {
+                    const int lo = vc < vt ? vc : vt, hi = vc < vt ? vt : vc;
+                    const uint32_t m_lo = (1u << lo) - 1u, m_hi = (1u << hi) - 1u;
+                    for (uint32_t i = tid; i < (nloc >> 2); i += T) {
+                        uint32_t b = ((i & ~m_lo) << 1) | (i & m_lo);
+                        b = ((b & ~m_hi) << 1) | (b & m_hi);
+                        const uint32_t i0 = b | (1u << vc);
                         const uint32_t i1 = i0 | (1u << vt);
                         const double2 a0 = state[i0];
                         state[i0] = state[i1];
                         state[i1] = a0;
                     }
                 }
-            } else {
-                const int lo = vc < vt ? vc : vt, hi = vc < vt ? vt : vc;
-                const uint32_t m_lo = (1u << lo) - 1u, m_hi = (1u << (hi - 1)) - 1u;
+            } else {  // ST_ECR on (q0 = va, q1 = vb); matrix index = 2*bit(q1) + bit(q0)
+                const int v0 = st.va, v1 = st.vb;
+                const int lo = v0 < v1 ? v0 : v1, hi = v0 < v1 ? v1 : v0;
+                const uint32_t m_lo = (1u << lo) - 1u, m_hi = (1u << hi) - 1u;
+                const double r = 0.70710678118654752440;
                 for (uint32_t i = tid; i < (nloc >> 2); i += T) {
-                    uint32_t b = ((i & ~m_lo) << 1) | (i & m_lo);      // zero at lo
-                    b = ((b & ~((m_hi << 1) | 1u)) << 1) | (b & ((m_hi << 1) | 1u));  // zero at hi
-                    const uint32_t i0 = b | (1u << vc);
-                    const uint32_t i1 = i0 | (1u << vt);
-                    const double2 a0 = state[i0];
-                    state[i0] = state[i1];
-                    state[i1] = a0;
+                    uint32_t b = ((i & ~m_lo) << 1) | (i & m_lo);
+                    b = ((b & ~m_hi) << 1) | (b & m_hi);
+                    const uint32_t j0 = b, j1 = b | (1u << v0), j2 = b | (1u << v1), j3 = j1 | (1u << v1);
+                    const double2 a0 = state[j0], a1 = state[j1], a2 = state[j2], a3 = state[j3];
+                    // 1/sqrt2 * [[0,1,0,i],[1,0,-i,0],[0,i,0,1],[-i,0,1,0]]
+                    state[j0] = make_double2(r * (a1.x - a3.y), r * (a1.y + a3.x));
+                    state[j1] = make_double2(r * (a0.x + a2.y), r * (a0.y - a2.x));
+                    state[j2] = make_double2(r * (a3.x - a1.y), r * (a3.y + a1.x));
+                    state[j3] = make_double2(r * (a2.x + a0.y), r * (a2.y - a0.x));
                 }
             }
-        } else {  // ST_ECR on (q0 = va, q1 = vb); matrix index = 2*bit(q1) + bit(q0)
-            const int v0 = st.va, v1 = st.vb;
-            const int lo = v0 < v1 ? v0 : v1, hi = v0 < v1 ? v1 : v0;
-            const uint32_t m_lo = (1u << lo) - 1u;
-            const uint32_t m_hi2 = (1u << hi) - 1u;  // mask below hi after inserting lo
-            const double r = 0.70710678118654752440;
-            for (uint32_t i = tid; i < (nloc >> 2); i += T) {
-                uint32_t b = ((i & ~m_lo) << 1) | (i & m_lo);
-                b = ((b & ~m_hi2) << 1) | (b & m_hi2);
-                const uint32_t j0 = b, j1 = b | (1u << v0), j2 = b | (1u << v1), j3 = j1 | (1u << v1);
-                const double2 a0 = state[j0], a1 = state[j1], a2 = state[j2], a3 = state[j3];
-                // 1/sqrt2 * [[0,1,0,i],[1,0,-i,0],[0,i,0,1],[-i,0,1,0]]
-                state[j0] = make_double2(r * (a1.x - a3.y), r * (a1.y + a3.x));
-                state[j1] = make_double2(r * (a0.x + a2.y), r * (a0.y - a2.x));
-                state[j2] = make_double2(r * (a3.x - a1.y), r * (a3.y + a1.x));
-                state[j3] = make_double2(r * (a2.x + a0.y), r * (a2.y - a0.x));
-            }
+            __syncthreads();
         }
-        __syncthreads();
+        // ---- write back (amplitudes that are still known-zero are left to the next pass) ------
+        for (uint32_t l = tid; l < nloc; l += T)
+            if (!(l & a.zero_out)) gpsi[chunk_phys | deposit(l, a)] = state[l];
+        __syncthreads();  // LDS is reused by the next item
     }
-    // ---- write back -----------------------------------------------------------
-    for (uint32_t l = tid; l < nloc; l += T) gpsi[chunk_phys | deposit(l, a)] = state[l];
 }
 
 int upload_circuit(qk_circuit& c) {
@@ -285,7 +365,8 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
     const int n = c.n_qubits;
     static bool attr_set = false;
     if (!attr_set) {
-        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     for (const Pass& ps : c.passes) {
@@ -295,7 +376,7 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
         a.psi = (double2*)psi_dev;
         a.D = (int64_t)1 << n;
         a.stages = c.d_stages + ps.stage_off;
-        a.terms = c.d_terms;
+        a.terms = c.d_terms + ps.term_off;
         a.exprs = c.d_exprs + ps.expr_off;
         a.mats = c.d_mats + ps.mat_off;
         a.prog = c.d_prog;
@@ -303,16 +384,32 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
         a.n_stage = ps.n_stage;
         a.n_expr = ps.n_expr;
         a.n_mat = ps.n_mat;
+        a.n_term = ps.n_term;
         a.L = ps.L;
-        a.lgT = ps.lgT;
+        a.h = ps.h;
         a.n_qubits = n;
         a.first = ps.first ? 1 : 0;
+        a.zero_in = ps.zero_in;
+        a.zero_out = ps.zero_out;
         a.nruns = ps.nruns;
         for (int r = 0; r < ps.nruns; ++r) { a.run_mask[r] = ps.run_mask[r]; a.run_shift[r] = ps.run_shift[r]; }
-        const int64_t nblocks = N << (n - ps.L);
-        if (nblocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: too many workgroups; split N");
-        const size_t lds = ((size_t)16 << ps.L) + (size_t)16 * ps.n_expr + (size_t)64 * ps.n_mat;
-        hipLaunchKernelGGL(sim_pass_kernel, dim3((unsigned)nblocks), dim3(1u << ps.lgT), lds, (hipStream_t)stream, a);
+        const int nchunk_bits = n - ps.L;
+        a.live_chunks = ((1u << nchunk_bits) - 1u) & ~(ps.zero_out >> ps.L);
+        a.nlive = __builtin_popcount(a.live_chunks);
+        if ((N >> (62 - a.nlive)) != 0) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
+        a.n_items = N << a.nlive;
+        const size_t lds = ((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
+                           (size_t)16 * ((1u << ps.h) + (1u << (ps.L - ps.h)));
+        const int threads = 1 << ps.lgT;
+        // resident workgroups per CU: LDS, and registers (MAXG = 3: 2 waves/SIMD; MAXG = 2: 3 waves/SIMD)
+        const int by_regs = (ps.maxg >= 3 ? 512 : 768) / threads;
+        int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)by_regs);
+        per_cu = std::max(1, std::min(per_cu, 16));
+        const int64_t nblocks = std::min<int64_t>(a.n_items, (int64_t)256 * per_cu);
+        if (ps.maxg >= 3)
+            hipLaunchKernelGGL(sim_pass_kernel<3>, dim3((unsigned)nblocks), dim3(threads), lds, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(sim_pass_kernel<2>, dim3((unsigned)nblocks), dim3(threads), lds, (hipStream_t)stream, a);
         QK_HIP(hipGetLastError());
     }
     return QK_OK;
