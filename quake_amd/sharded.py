@@ -158,3 +158,35 @@ class ShardedGram:
             # sender computed rows a0:a1 x my rows b0:b1 and sent the transpose [b, a]
             K_block[t.b0 - g0:t.b1 - g0, t.a0:t.a1].copy_(buf)
         return K_block
+
+
+def sharded_projected_kernel(rdm_local, gamma: float, rank: int = 0, world: int = 1, group=None, pqk_fn=None):
+    """Projected-kernel row block on one rank (config 4 of BASELINE.json).
+
+    Each rank has simulated its row shard and reduced it to the per-qubit RDM table
+    ``rdm_local`` (float64 ``[N/G, n, 4]``, a few hundred bytes per sample).  The ONE exchange is
+    an all-gather of that table -- the statevectors never leave their GPU -- after which the rank
+    evaluates its ``[N/G, N]`` block of ``exp(-gamma * sum_q ||rho_i - rho_j||_F)``.  The block on
+    the diagonal is computed as a symmetric block so ``K[i, i]`` is exactly 1 as in the reference
+    (genetic_v3.py:805).  ``pqk_fn(rdm_x, rdm_y_or_None, gamma, out)`` defaults to the HIP launcher."""
+    import torch
+    import torch.distributed as dist
+
+    if pqk_fn is None:
+        from .device import pqk as pqk_fn
+    nloc = rdm_local.shape[0]
+    rdm_local = rdm_local.contiguous()
+    if world == 1:
+        out = torch.empty((nloc, nloc), dtype=torch.float64, device=rdm_local.device)
+        pqk_fn(rdm_local, None, gamma, out)
+        return out
+    table = torch.empty((world * nloc,) + tuple(rdm_local.shape[1:]), dtype=rdm_local.dtype, device=rdm_local.device)
+    dist.all_gather_into_tensor(table, rdm_local, group=group)
+    out = torch.empty((nloc, world * nloc), dtype=torch.float64, device=rdm_local.device)
+    r0 = rank * nloc
+    if r0 > 0:
+        pqk_fn(rdm_local, table[:r0], gamma, out[:, :r0])
+    pqk_fn(rdm_local, None, gamma, out[:, r0:r0 + nloc])
+    if r0 + nloc < world * nloc:
+        pqk_fn(rdm_local, table[r0 + nloc:], gamma, out[:, r0 + nloc:])
+    return out

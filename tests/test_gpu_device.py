@@ -1,0 +1,77 @@
+"""Device-resident entry points (torch tensors in HBM -> *_dev C ABI) against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import qk_oracle as O
+from tests._helpers import synth_X
+from tests.test_sharded_cpu import _rdm_table
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, N, builder, repeats=1, seed=3):
+    import torch
+    from quake_amd import device as dev, featuremaps as fm
+    from quake_amd.circuit import ParameterVector
+    X = synth_X(N, n, "scaled", seed)
+    circ = dev.DeviceCircuit(getattr(fm, builder)(ParameterVector("x", n), n, repeats))
+    oops = getattr(O, builder)(n, repeats)
+    return torch, dev, circ, oops, X
+
+
+@pytest.mark.parametrize("n,N", [(3, 50), (9, 70), (12, 40), (13, 9), (14, 5)])
+def test_rdm1_and_pqk_blocks(n, N):
+    torch, dev, circ, oops, X = _setup(n, N, "custom1_featuremap", 1)
+    psi = circ.simulate(torch.from_numpy(X).cuda())
+    rd = dev.rdm1(psi, n)
+    ref = _rdm_table(O.statevectors(oops, n, X), n)
+    assert np.abs(rd.cpu().numpy() - ref).max() < 1e-13
+    Kref = O.projected_kernel(oops, n, X, 0.6)
+    K = dev.pqk(rd, None, 0.6)
+    assert np.abs(K.cpu().numpy() - Kref).max() < 1e-12
+    # cross block into a strided view
+    big = torch.full((N, N + 7), -2.0, dtype=torch.float64, device="cuda")
+    m = N // 2
+    dev.pqk(rd[:m], rd[m:], 0.6, out=big[:m, 3:3 + N - m])
+    got = big.cpu().numpy()
+    assert np.abs(got[:m, 3:3 + N - m] - Kref[:m, m:]).max() < 1e-12
+    assert (got[:, :3] == -2).all() and (got[m:] == -2).all() and (got[:, 3 + N - m:] == -2).all()
+
+
+def test_sharded_single_rank_paths():
+    from quake_amd import sharded
+    n, N = 8, 300
+    torch, dev, circ, oops, X = _setup(n, N, "zz_featuremap", 2)
+    psi = circ.simulate(torch.from_numpy(X).cuda())
+    K = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    sharded.ShardedGram(N, 1 << n, 0, 1).compute(psi, K)
+    assert np.abs(K.cpu().numpy() - O.evaluate(oops, n, X)).max() < 1e-12
+    Kp = sharded.sharded_projected_kernel(dev.rdm1(psi, n), 1.0)
+    assert np.abs(Kp.cpu().numpy() - O.projected_kernel(oops, n, X, 1.0)).max() < 1e-12
+
+
+def test_multi_job_launch_matches_plan():
+    """The 4-GPU plan of rank 1 executed on ONE GPU: every job of the rank in one launch, mirrored
+    blocks land transposed in their staging buffers."""
+    from quake_amd import sharded
+    n, N, world, rank = 7, 4 * 96, 4, 1
+    torch, dev, circ, oops, X = _setup(n, N, "zz_featuremap", 1)
+    psi = circ.simulate(torch.from_numpy(X).cuda())
+    Kref = O.evaluate(oops, n, X)
+    tasks = sharded.plan_tasks(rank, world, N)
+    g0, g1 = sharded.row_range(rank, world, N)
+    Kb = torch.full((g1 - g0, N), -1.0, dtype=torch.float64, device="cuda")
+    jobs, sends = [], []
+    for t in tasks:
+        j = dict(A=psi[t.a0:t.a1], B=psi[t.b0:t.b1], K=Kb[t.a0 - g0:t.a1 - g0, t.b0:t.b1], symmetric=t.symmetric)
+        if not t.symmetric:
+            j["KT"] = torch.empty((t.b1 - t.b0, t.a1 - t.a0), dtype=torch.float64, device="cuda")
+            sends.append((t, j["KT"]))
+        jobs.append(j)
+    dev.gram_jobs(jobs, 1 << n)
+    torch.cuda.synchronize()
+    got = Kb.cpu().numpy()
+    for t in tasks:
+        assert np.abs(got[t.a0 - g0:t.a1 - g0, t.b0:t.b1] - Kref[t.a0:t.a1, t.b0:t.b1]).max() < 1e-12
+    for t, buf in sends:
+        assert np.abs(buf.cpu().numpy() - Kref[t.b0:t.b1, t.a0:t.a1]).max() < 1e-12

@@ -91,3 +91,41 @@ def _free_port():
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_gram_over_gloo(world):
     mp.spawn(_worker, args=(world, _free_port(), 8 * world, 4), nprocs=world, join=True)
+
+
+def _cpu_pqk(rdm_x, rdm_y, gamma, out):
+    x = rdm_x.numpy()
+    y = x if rdm_y is None else rdm_y.numpy()
+    d = x[:, None] - y[None]                                   # (Nx, Ny, n, 4)
+    fro = np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2 + 2 * (d[..., 2] ** 2 + d[..., 3] ** 2))
+    K = np.exp(-gamma * fro.sum(axis=2))
+    if rdm_y is None:
+        np.fill_diagonal(K, 1.0)
+    out.copy_(torch.from_numpy(K))
+    return out
+
+
+def _rdm_table(psi, n):
+    r = O.rdm1(psi, n)
+    return np.stack([r[..., 0, 0].real, r[..., 1, 1].real, r[..., 0, 1].real, r[..., 0, 1].imag], axis=-1)
+
+
+def _pqk_worker(rank, world, port, N, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = np.random.default_rng(9).uniform(-1.5, 1.5, size=(N, n))
+        ops = O.zz_featuremap(n, 1)
+        r0, r1 = sharded.row_range(rank, world, N)
+        local = torch.from_numpy(np.ascontiguousarray(_rdm_table(O.statevectors(ops, n, X[r0:r1]), n)))
+        K = sharded.sharded_projected_kernel(local, 0.8, rank, world, pqk_fn=_cpu_pqk)
+        ref = O.projected_kernel(ops, n, X, 0.8)[r0:r1]
+        assert np.abs(K.numpy() - ref).max() < 1e-13
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_projected_kernel_over_gloo(world):
+    mp.spawn(_pqk_worker, args=(world, _free_port(), 6 * world, 3), nprocs=world, join=True)
