@@ -74,6 +74,23 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     }
     c.n_gates = (int)items.size();
 
+    // A single-qubit gate that is the very first operation on its qubit acts on |0> and commutes
+    // with everything before it: all of those are hoisted to the start of the circuit, where they
+    // turn |0...0> into a product state the first pass writes directly (ST_INIT) -- no sweeps and
+    // no need for the qubit to be local.
+    std::vector<Item> inits;
+    {
+        std::vector<Item> rest;
+        uint32_t touched = 0;
+        for (const Item& it : items) {
+            if (!it.diag && it.kind == ST_U1 && !((touched >> it.q0) & 1u)) inits.push_back(it);
+            else rest.push_back(it);
+            touched |= 1u << it.q0;
+            if (it.q1 >= 0) touched |= 1u << it.q1;
+        }
+        items.swap(rest);
+    }
+
     // ---- 2. merge diagonal runs, sinking them past commuting gates ---------
     std::vector<Proto> seq;
     std::vector<Item> pending;
@@ -106,49 +123,61 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     flush();
 
     // ---- 3. passes --------------------------------------------------------
-    const int Lmax = std::min(n, kMaxLocalQubits);
-    const int n_fixed = (n > Lmax) ? std::min(4, n) : 0;  // low qubits kept local: 256-B runs in HBM
     struct Draft { std::vector<int> S; std::vector<int> stage_ids; int n_term = 0, n_mat = 0; };
-    std::vector<Draft> drafts;
-    auto new_draft = [&]() {
-        Draft d;
-        if (n <= Lmax) {
-            for (int q = 0; q < n; ++q) d.S.push_back(q);
-        } else {
-            for (int q = 0; q < n_fixed; ++q) d.S.push_back(q);
-        }
-        drafts.push_back(d);
-    };
-    new_draft();
-    for (int s = 0; s < (int)seq.size(); ++s) {
-        const Proto& p = seq[s];
-        std::vector<int> need;
-        int add_term = 0, add_mat = 0;
-        if (p.diag) {
-            add_term = (int)p.terms.size();
-        } else {
-            if (p.nd.kind == ST_U1) { need = {p.nd.q0}; add_mat = 1; }
-            if (p.nd.kind == ST_CX) need = {p.nd.q1};
-            if (p.nd.kind == ST_ECR) need = {p.nd.q0, p.nd.q1};
-        }
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            Draft& d = drafts.back();
-            std::vector<int> S2 = d.S;
-            for (int q : need)
-                if (std::find(S2.begin(), S2.end(), q) == S2.end()) S2.push_back(q);
-            const bool fits = (int)S2.size() <= Lmax && d.n_term + add_term <= kMaxTermPerPass &&
-                              d.n_mat + add_mat <= kMaxMatPerPass;
-            if (fits) {
-                d.S = S2;
-                d.stage_ids.push_back(s);
-                d.n_term += add_term;
-                d.n_mat += add_mat;
-                break;
+    // greedy split for a given number of local qubits; empty result = some gate cannot be placed
+    auto make_drafts = [&](int Lcap) {
+        const int n_fixed = (n > Lcap) ? std::min(4, n) : 0;  // low qubits kept local: 256-B runs in HBM
+        std::vector<Draft> drafts;
+        auto new_draft = [&]() {
+            Draft d;
+            for (int q = 0; q < (n <= Lcap ? n : n_fixed); ++q) d.S.push_back(q);
+            drafts.push_back(d);
+        };
+        new_draft();
+        drafts.back().n_mat = (int)inits.size();
+        for (int s = 0; s < (int)seq.size(); ++s) {
+            const Proto& p = seq[s];
+            std::vector<int> need;
+            int add_term = 0, add_mat = 0;
+            if (p.diag) {
+                add_term = (int)p.terms.size();
+            } else {
+                if (p.nd.kind == ST_U1) { need = {p.nd.q0}; add_mat = 1; }
+                if (p.nd.kind == ST_CX) need = {p.nd.q1};
+                if (p.nd.kind == ST_ECR) need = {p.nd.q0, p.nd.q1};
             }
-            if (attempt == 1) return fail(QK_ERR_UNSUPPORTED, "cannot place gate in a simulator pass");
-            new_draft();
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                Draft& d = drafts.back();
+                std::vector<int> S2 = d.S;
+                for (int q : need)
+                    if (std::find(S2.begin(), S2.end(), q) == S2.end()) S2.push_back(q);
+                const bool fits = (int)S2.size() <= Lcap && d.n_term + add_term <= kMaxTermPerPass &&
+                                  d.n_mat + add_mat <= kMaxMatPerPass;
+                if (fits) {
+                    d.S = S2;
+                    d.stage_ids.push_back(s);
+                    d.n_term += add_term;
+                    d.n_mat += add_mat;
+                    break;
+                }
+                if (attempt == 1) return std::vector<Draft>();
+                new_draft();
+            }
+        }
+        return drafts;
+    };
+    // 12 local qubits (64 KiB of state) let two workgroups share a CU, so one computes while the
+    // other is stuck behind its stores; 13 only where that saves a pass over HBM.
+    int Lmax = std::min(n, kMaxLocalQubits);
+    std::vector<Draft> drafts = make_drafts(Lmax);
+    if (Lmax == kMaxLocalQubits) {
+        std::vector<Draft> d12 = make_drafts(kMaxLocalQubits - 1);
+        if (!d12.empty() && (drafts.empty() || d12.size() <= drafts.size())) {
+            drafts.swap(d12);
+            Lmax = kMaxLocalQubits - 1;
         }
     }
+    if (drafts.empty()) return fail(QK_ERR_UNSUPPORTED, "cannot place gate in a simulator pass");
 
     c.passes.clear();
     uint32_t active = 0;  // qubits a non-diagonal gate has acted on so far
@@ -165,9 +194,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         Pass ps;
         ps.L = Lmax;
         ps.first = (pi == 0);
-        ps.lgT = ps.L >= 12 ? 9 : (ps.L >= 9 ? 8 : std::max(6, ps.L - 1));
-        ps.h = ps.L <= 8 ? ps.L : (ps.L + 1) / 2;
-        ps.maxg = ps.L >= 12 ? 3 : 2;   // radix-8 sweeps need the 512-thread / 256-VGPR kernel
+        ps.lgT = ps.L >= 13 ? 9 : (ps.L >= 9 ? 8 : std::max(6, ps.L - 1));
+        ps.h = ps.L <= 6 ? ps.L : 6;    // 64 columns = one wavefront; <= kMaxRowBits row bits
+        ps.maxg = ps.L >= 13 ? 3 : 2;   // radix-8 sweeps need the 512-thread / 256-VGPR kernel
         ps.phys = d.S;
         for (int q = 0; q < n; ++q)
             if (std::find(d.S.begin(), d.S.end(), q) == d.S.end()) ps.phys.push_back(q);
@@ -189,8 +218,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         ps.expr_off = (int)c.exprs.size();
         ps.mat_off = (int)c.mats.size();
         ps.term_off = (int)c.terms.size();
-        auto add_expr = [&](int e, double scale, int dst) {
-            c.exprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale, dst, 0});
+        auto add_expr = [&](int e, double scale, int dst, int gate = 0) {
+            c.exprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale, dst, gate});
         };
         auto mask_of = [&](uint32_t qubit_mask) {
             uint32_t m = 0;
@@ -198,6 +227,20 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 if (qubit_mask >> q & 1u) m |= 1u << virt[q];
             return m;
         };
+        if (pi == 0) {
+            for (const Item& g : inits) {
+                active |= 1u << g.q0;
+                c.mats.push_back(DevMat{g.gate, 0});
+                const int mi = (int)c.mats.size() - 1 - ps.mat_off;
+                if (g.expr >= 0) add_expr(g.expr, 0.5, ~mi, g.gate);
+                DevStage st{};
+                st.kind = ST_INIT;
+                st.va = virt[g.q0];
+                st.gm[0] = mi;
+                c.stages.push_back(st);
+            }
+            ps.n_init = (int)inits.size();
+        }
         ps.zero_in = mask_of(~active & ((n >= 32) ? 0xffffffffu : ((1u << n) - 1u)));
         for (int s : d.stage_ids) {
             const Proto& p = seq[s];
@@ -217,9 +260,16 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                     if (t.q1 >= 0) look(dt.vb);
                     (in_lo && in_hi ? cross : (in_hi ? hi : lo)).push_back({dt, t.expr});
                 }
+                auto row_bit = [&](const DevTerm& t) { return (t.va >= ps.h ? t.va : t.vb) - ps.h; };
+                std::stable_sort(cross.begin(), cross.end(),
+                                 [&](const auto& x, const auto& y) { return row_bit(x.first) < row_bit(y.first); });
                 st.nLo = (int)lo.size();
                 st.nHi = (int)hi.size();
                 st.nX = (int)cross.size();
+                for (int a = 0, k = 0; a <= kMaxRowBits; ++a) {
+                    while (k < st.nX && row_bit(cross[k].first) < a) ++k;
+                    st.xo[a] = k;
+                }
                 for (auto* grp : {&lo, &hi, &cross})
                     for (auto& te : *grp) {
                         c.terms.push_back(te.first);
@@ -234,13 +284,13 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 active |= 1u << g.q0;
                 c.mats.push_back(DevMat{g.gate, 0});
                 const int mi = (int)c.mats.size() - 1 - ps.mat_off;
-                if (g.expr >= 0) add_expr(g.expr, 0.5, ~mi);
+                if (g.expr >= 0) add_expr(g.expr, 0.5, ~mi, g.gate);
                 const int v = virt[g.q0];
                 // fuse with the previous stage if that is a U1 group in this pass without this qubit
                 bool fused = false;
                 if ((int)c.stages.size() > ps.stage_off) {
                     DevStage& prev = c.stages.back();
-                    if (prev.kind == ST_U1 && prev.ng < ps.maxg) {
+                    if (prev.kind == ST_U1 && prev.ng < ps.maxg && (int)c.stages.size() > ps.stage_off + ps.n_init) {
                         bool clash = false;
                         for (int k = 0; k < prev.ng; ++k) clash |= (prev.gv[k] == v);
                         if (!clash) {

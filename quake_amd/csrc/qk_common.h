@@ -28,7 +28,8 @@ int fail(int code, const std::string& msg);
 // Inside a pass every qubit has a *virtual* bit position: local qubits take
 // 0..L-1 (ascending qubit order), chunk qubits take L..n-1.
 
-enum StageKind : int32_t { ST_DIAG = 0, ST_U1 = 1, ST_CX = 2, ST_ECR = 3 };
+enum StageKind : int32_t { ST_DIAG = 0, ST_U1 = 1, ST_CX = 2, ST_ECR = 3, ST_INIT = 4 };
+constexpr int kMaxRowBits = 7;  // a diagonal stage splits the local bits into h "column" and <= 7 "row" bits
 constexpr int kMaxGroup = 3;  // single-qubit gates on distinct qubits fused into one radix-8 sweep
 enum TermKind : int32_t { TM_P = 0, TM_RZ = 1, TM_CZ = 2, TM_ZZP = 3 };
 
@@ -40,20 +41,24 @@ struct DevTerm {      // one factor of a diagonal stage (device table)
 
 struct DevStage {
     int32_t kind;     // StageKind
-    int32_t va, vb;   // CX: va = control, vb = target; ECR: va = q0, vb = q1
+    int32_t va, vb;   // CX: va = control, vb = target; ECR: va = q0, vb = q1; INIT: va = the qubit
     int32_t ng;       // U1: number of fused gates (1..kMaxGroup), on distinct local qubits
     int32_t gv[kMaxGroup];  // U1: target bits, ascending
     int32_t gm[kMaxGroup];  // U1: pass-local matrix index of the gate on gv[k]
     // DIAG: pass-local terms [t0, t0+nLo) depend on local bits < h only (plus chunk bits),
-    // the next nHi on local bits >= h only, the last nX on both halves
+    // the next nHi on local bits >= h only, the last nX on one bit of each half; those are sorted
+    // by their row bit: the terms with row bit h+a are [xo[a], xo[a+1]) of the nX
     int32_t t0, nLo, nHi, nX;
+    int32_t xo[kMaxRowBits + 1];
+    // INIT: the first gate on a still-|0> qubit (virtual bit va, local or chunk):
+    //       amplitude *= entry [bit va][0] of matrix gm[0]
 };
 
 struct DevExpr {      // one gate angle evaluated per sample
     int32_t start, len;   // slice of the postfix program
     double scale;         // 0.5 for rx/ry/rz (half angle), 1 for p
     int32_t dst;          // >= 0: pass-local term that takes (cos, sin); < 0: matrix ~dst
-    int32_t pad;
+    int32_t gate;         // qk_gate of that matrix (rx / ry), 0 for terms
 };
 
 struct DevMat {       // a 2x2 matrix: constant for h / x / sx, filled from its angle for rx / ry
@@ -77,6 +82,9 @@ struct Pass {
     // loaded; zero_out: those still untouched after a pass that is not the last -- not stored
     // (the next pass knows they are zero).
     uint32_t zero_in = 0, zero_out = 0;
+    // First pass only: the leading n_init stages are ST_INIT, the hoisted first gates (see the
+    // planner).  The pass starts from the product state they make instead of |0...0>.
+    int n_init = 0;
     std::vector<int> phys;     // phys[v] = physical qubit at virtual position v (size n)
     int stage_off = 0, n_stage = 0;
     int expr_off = 0, n_expr = 0;

@@ -31,8 +31,10 @@ struct SimArgs {
     const qk_instr* prog;
     const double* consts;
     int n_stage, n_expr, n_mat, n_term;
-    int L, h, n_qubits, first;
+    int n_prog, n_consts, n_params, staged;   // staged: exprs / prog / consts are copied to LDS
+    int L, h, lgT, n_qubits, first;
     uint32_t zero_in, zero_out;  // virtual-bit masks of still-|0> qubits (see Pass)
+    int n_init;                  // first pass: leading ST_INIT stages (hoisted first gates)
     uint32_t live_chunks;        // chunk-index bits that are not known-zero after the pass
     int nlive;                   // popcount(live_chunks)
     int64_t n_items;             // N << nlive (sample, live chunk) pairs
@@ -88,17 +90,21 @@ __device__ __forceinline__ void apply_term(const RTerm& t, uint32_t w, double& f
 }
 
 template <int NG>
-__device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, const DevStage& st, uint32_t nloc,
-                                         int tid, int T) {
+__device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, const DevMat* mats, const DevStage& st,
+                                         uint32_t nloc, int tid, int T) {
     // NG single-qubit gates on distinct local qubits in one sweep: each thread holds the 2^NG
-    // amplitudes that differ in the target bits and applies the gates in registers
+    // amplitudes that differ in the target bits and applies the gates in registers.
+    // form: 0 = real matrix (h, x, ry), 1 = real diagonal + imaginary off-diagonal (rx), 2 = general (sx)
     double2 m[NG][4];
     uint32_t lm[NG];
+    int form[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[g][k] = mat[4 * st.gm[g] + k];
         lm[g] = (1u << st.gv[g]) - 1u;
+        const int gate = mats[st.gm[g]].gate;
+        form[g] = (gate == QK_H || gate == QK_X || gate == QK_RY) ? 0 : (gate == QK_RX ? 1 : 2);
     }
     for (uint32_t i = tid; i < (nloc >> NG); i += T) {
         uint32_t b = i;
@@ -115,17 +121,85 @@ __device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, con
             v[k] = state[o];
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
+        for (int g = 0; g < NG; ++g) {
+            if (form[g] == 0) {
 #pragma unroll
-            for (int k = 0; k < (1 << NG); ++k)
-                if (!((k >> g) & 1)) {
-                    const int k1 = k | (1 << g);
-                    const double2 a0 = v[k], a1 = v[k1];
-                    v[k] = cfma(m[g][1], a1, cmul(m[g][0], a0));
-                    v[k1] = cfma(m[g][3], a1, cmul(m[g][2], a0));
-                }
+                for (int k = 0; k < (1 << NG); ++k)
+                    if (!((k >> g) & 1)) {
+                        const int k1 = k | (1 << g);
+                        const double2 a0 = v[k], a1 = v[k1];
+                        v[k] = make_double2(fma(m[g][1].x, a1.x, m[g][0].x * a0.x), fma(m[g][1].x, a1.y, m[g][0].x * a0.y));
+                        v[k1] = make_double2(fma(m[g][3].x, a1.x, m[g][2].x * a0.x), fma(m[g][3].x, a1.y, m[g][2].x * a0.y));
+                    }
+            } else if (form[g] == 1) {
+#pragma unroll
+                for (int k = 0; k < (1 << NG); ++k)
+                    if (!((k >> g) & 1)) {
+                        const int k1 = k | (1 << g);
+                        const double2 a0 = v[k], a1 = v[k1];
+                        // (i y)(a.x + i a.y) = -y a.y + i y a.x
+                        v[k] = make_double2(fma(-m[g][1].y, a1.y, m[g][0].x * a0.x), fma(m[g][1].y, a1.x, m[g][0].x * a0.y));
+                        v[k1] = make_double2(fma(-m[g][2].y, a0.y, m[g][3].x * a1.x), fma(m[g][2].y, a0.x, m[g][3].x * a1.y));
+                    }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (1 << NG); ++k)
+                    if (!((k >> g) & 1)) {
+                        const int k1 = k | (1 << g);
+                        const double2 a0 = v[k], a1 = v[k1];
+                        v[k] = cfma(m[g][1], a1, cmul(m[g][0], a0));
+                        v[k1] = cfma(m[g][3], a1, cmul(m[g][2], a0));
+                    }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < (1 << NG); ++k) state[idx[k]] = v[k];
+    }
+}
+
+// The per-sample gate angles: one thread per angle runs its postfix program (validated on the
+// host: qk_circuit_create) and leaves (cos, sin) in the diagonal term or the 2x2 matrix it feeds.
+// Called once with the tables staged in LDS and once with them in global memory, so each copy
+// is compiled for one address space.
+template <class ExprPtr, class ProgPtr, class ConstPtr>
+__device__ __forceinline__ void run_angle_programs(ExprPtr exprs, ProgPtr prog, ConstPtr consts, const double* xrow,
+                                                   int n_expr, RTerm* rt, double2* mat, int tid, int T) {
+    for (int e = tid; e < n_expr; e += T) {
+        const DevExpr ex = exprs[e];
+        double st[8];
+        int sp = 0;
+        for (int k = 0; k < ex.len; ++k) {
+            const qk_instr in = prog[ex.start + k];
+            switch (in.op) {
+                case QK_EX_CONST: st[sp++] = consts[in.arg]; break;
+                case QK_EX_PARAM: st[sp++] = xrow[in.arg]; break;
+                case QK_EX_ADD: --sp; st[sp - 1] = st[sp - 1] + st[sp]; break;
+                case QK_EX_SUB: --sp; st[sp - 1] = st[sp - 1] - st[sp]; break;
+                case QK_EX_MUL: --sp; st[sp - 1] = st[sp - 1] * st[sp]; break;
+                case QK_EX_DIV: --sp; st[sp - 1] = st[sp - 1] / st[sp]; break;
+                case QK_EX_NEG: st[sp - 1] = -st[sp - 1]; break;
+                case QK_EX_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
+                case QK_EX_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
+                case QK_EX_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+                case QK_EX_COS: st[sp - 1] = cos(st[sp - 1]); break;
+                default: break;
+            }
+        }
+        double sn, cn;
+        sincos(st[0] * ex.scale, &sn, &cn);
+        if (ex.dst >= 0) {
+            rt[ex.dst].c = cn;
+            rt[ex.dst].s = sn;
+        } else {  // rx / ry from cos, sin of theta/2
+            const int m = ~ex.dst;
+            if (ex.gate == QK_RX) {
+                mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(0, -sn);
+                mat[4 * m + 2] = make_double2(0, -sn); mat[4 * m + 3] = make_double2(cn, 0);
+            } else {
+                mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(-sn, 0);
+                mat[4 * m + 2] = make_double2(sn, 0); mat[4 * m + 3] = make_double2(cn, 0);
+            }
+        }
     }
 }
 
@@ -140,12 +214,60 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, MAXG == 3 ? 2 : 3) sim_
     double2* mat = (double2*)(rt + a.n_term);               // n_mat * 4 complex entries
     double2* tlo = mat + 4 * a.n_mat;                       // phase table over local bits < h
     double2* thi = tlo + (1u << h);                         // phase table over local bits >= h
+    double2* rat = thi + (1u << (L - h));                   // [row bit][column]: cross-term ratio of setting that bit
+    double* xbuf = (double*)(rat + ((uint32_t)(L - h) << h));   // feature rows of this item and the next
+    const int xs = (a.n_params + 1) & ~1;
+    DevExpr* s_expr = (DevExpr*)(xbuf + 2 * xs);            // staged angle programs (a.staged)
+    qk_instr* s_prog = (qk_instr*)(s_expr + a.n_expr);
+    double* s_const = (double*)(s_prog + a.n_prog);
+    int2* s_init = (int2*)(s_const + a.n_consts);           // (virtual bit, matrix) of the hoisted first gates
     const int tid = threadIdx.x;
     const int T = blockDim.x;
+
+    // ---- once per workgroup: everything that does not depend on the sample -----------------
+    for (int t = tid; t < a.n_term; t += T) {
+        const DevTerm d = a.terms[t];
+        RTerm r;
+        r.c = -1.0; r.s = 0.0;            // TM_CZ; parametric terms get their (cos, sin) per item
+        r.type = d.type; r.va = d.va; r.vb = d.vb; r.pad = 0;
+        rt[t] = r;
+    }
+    for (int m = tid; m < a.n_mat; m += T) {
+        const int gate = a.mats[m].gate;
+        const double r = 0.70710678118654752440;
+        double2 m00 = make_double2(0, 0), m01 = m00, m10 = m00, m11 = m00;
+        if (gate == QK_H) {
+            m00 = make_double2(r, 0); m01 = make_double2(r, 0); m10 = make_double2(r, 0); m11 = make_double2(-r, 0);
+        } else if (gate == QK_X) {
+            m01 = make_double2(1, 0); m10 = make_double2(1, 0);
+        } else if (gate == QK_SX) {
+            m00 = make_double2(0.5, 0.5); m01 = make_double2(0.5, -0.5);
+            m10 = make_double2(0.5, -0.5); m11 = make_double2(0.5, 0.5);
+        }
+        mat[4 * m + 0] = m00; mat[4 * m + 1] = m01; mat[4 * m + 2] = m10; mat[4 * m + 3] = m11;
+    }
+    if (!a.staged) s_init = (int2*)(xbuf + 2 * xs);
+    for (int k = tid; k < a.n_init; k += T) s_init[k] = make_int2(a.stages[k].va, a.stages[k].gm[0]);
+    if (a.staged) {
+        for (int e = tid; e < a.n_expr; e += T) s_expr[e] = a.exprs[e];
+        for (int k = tid; k < a.n_prog; k += T) s_prog[k] = a.prog[k];
+        for (int k = tid; k < a.n_consts; k += T) s_const[k] = a.consts[k];
+    }
+    if ((int64_t)blockIdx.x < a.n_items)
+        for (int t = tid; t < a.n_params; t += T) xbuf[t] = a.X[((int64_t)blockIdx.x >> a.nlive) * a.ldx + t];
+    __syncthreads();
+
     // Persistent workgroups: each walks (sample, chunk) items with a grid stride, so the launch cost
     // is paid once per CU slot.  Chunks whose amplitudes are all still zero after the pass (and a
-    // later pass knows) are not items at all.
-    for (int64_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    // later pass knows) are not items at all.  In steady state the only vector-memory traffic of a
+    // first pass is the store of the chunk and the prefetch of the next feature row, so the stores
+    // of one item drain while the next is computed.
+    int par = 0;
+    for (int64_t item = blockIdx.x; item < a.n_items; item += gridDim.x, par ^= 1) {
+        const int64_t next = item + gridDim.x;
+        const bool have_next = next < a.n_items && tid < a.n_params;
+        double xnext = 0.0;
+        if (have_next) xnext = a.X[(next >> a.nlive) * a.ldx + tid];   // in flight until the end of the item
         uint32_t chunk = 0;
         {
             uint32_t ci = (uint32_t)(item & ((1u << a.nlive) - 1u)), m = a.live_chunks;
@@ -153,118 +275,132 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, MAXG == 3 ? 2 : 3) sim_
                 if (m & 1u) { chunk |= (ci & 1u) << b; ci >>= 1; }
         }
         const int64_t sample = item >> a.nlive;
-        const double* xrow = a.X + sample * a.ldx;
+        const double* xrow = xbuf + par * xs;
         const uint32_t whi = chunk << L;
 
-        // ---- static parts of the tables: term kinds/bits, constant matrices ----------
-        for (int t = tid; t < a.n_term; t += T) {
-            const DevTerm d = a.terms[t];
-            RTerm r;
-            r.c = -1.0; r.s = 0.0;            // TM_CZ; parametric terms get their (cos, sin) below
-            r.type = d.type; r.va = d.va; r.vb = d.vb; r.pad = 0;
-            rt[t] = r;
-        }
-        for (int m = tid; m < a.n_mat; m += T) {
-            const int gate = a.mats[m].gate;
-            const double r = 0.70710678118654752440;
-            double2 m00 = make_double2(0, 0), m01 = m00, m10 = m00, m11 = m00;
-            if (gate == QK_H) {
-                m00 = make_double2(r, 0); m01 = make_double2(r, 0); m10 = make_double2(r, 0); m11 = make_double2(-r, 0);
-            } else if (gate == QK_X) {
-                m01 = make_double2(1, 0); m10 = make_double2(1, 0);
-            } else if (gate == QK_SX) {
-                m00 = make_double2(0.5, 0.5); m01 = make_double2(0.5, -0.5);
-                m10 = make_double2(0.5, -0.5); m11 = make_double2(0.5, 0.5);
-            }
-            mat[4 * m + 0] = m00; mat[4 * m + 1] = m01; mat[4 * m + 2] = m10; mat[4 * m + 3] = m11;
-        }
-        // ---- initial state / chunk load -------------------------------------------------
+        // ---- chunk load -----------------------------------------------------------------
         // amplitudes with a bit of a still-|0> qubit set are zero by construction: never loaded
         const uint32_t chunk_phys = deposit(whi, a);
         double2* gpsi = a.psi + sample * a.D;
-        if (a.first || (whi & a.zero_in)) {
-            for (uint32_t l = tid; l < nloc; l += T) state[l] = make_double2(0.0, 0.0);
-        } else {
-            for (uint32_t l = tid; l < nloc; l += T)
-                state[l] = (l & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | deposit(l, a)];
+        if (!a.first) {
+            if (whi & a.zero_in) {
+                for (uint32_t l = tid; l < nloc; l += T) state[l] = make_double2(0.0, 0.0);
+            } else {
+                for (uint32_t l = tid; l < nloc; l += T)
+                    state[l] = (l & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | deposit(l, a)];
+            }
         }
-        __syncthreads();
-        if (a.first && chunk == 0 && tid == 0) state[0] = make_double2(1.0, 0.0);
         // ---- per-sample gate angles -> (cos, sin) into their term or matrix ---------------
-        for (int e = tid; e < a.n_expr; e += T) {
-            const DevExpr ex = a.exprs[e];
-            double st[8];
-            int sp = 0;
-            for (int k = 0; k < ex.len; ++k) {
-                const qk_instr in = a.prog[ex.start + k];
-                switch (in.op) {
-                    case QK_EX_CONST: st[sp++] = a.consts[in.arg]; break;
-                    case QK_EX_PARAM: st[sp++] = xrow[in.arg]; break;
-                    case QK_EX_ADD: --sp; st[sp - 1] = st[sp - 1] + st[sp]; break;
-                    case QK_EX_SUB: --sp; st[sp - 1] = st[sp - 1] - st[sp]; break;
-                    case QK_EX_MUL: --sp; st[sp - 1] = st[sp - 1] * st[sp]; break;
-                    case QK_EX_DIV: --sp; st[sp - 1] = st[sp - 1] / st[sp]; break;
-                    case QK_EX_NEG: st[sp - 1] = -st[sp - 1]; break;
-                    case QK_EX_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
-                    case QK_EX_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
-                    case QK_EX_SIN: st[sp - 1] = sin(st[sp - 1]); break;
-                    case QK_EX_COS: st[sp - 1] = cos(st[sp - 1]); break;
-                    default: break;
-                }
-            }
-            double sn, cn;
-            sincos(st[0] * ex.scale, &sn, &cn);
-            if (ex.dst >= 0) {
-                rt[ex.dst].c = cn;
-                rt[ex.dst].s = sn;
-            } else {  // rx / ry from cos, sin of theta/2
-                const int m = ~ex.dst;
-                if (a.mats[m].gate == QK_RX) {
-                    mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(0, -sn);
-                    mat[4 * m + 2] = make_double2(0, -sn); mat[4 * m + 3] = make_double2(cn, 0);
-                } else {
-                    mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(-sn, 0);
-                    mat[4 * m + 2] = make_double2(sn, 0); mat[4 * m + 3] = make_double2(cn, 0);
-                }
-            }
-        }
+        if (a.staged) run_angle_programs(s_expr, s_prog, s_const, xrow, a.n_expr, rt, mat, tid, T);
+        else run_angle_programs(a.exprs, a.prog, a.consts, xrow, a.n_expr, rt, mat, tid, T);
         __syncthreads();
 
+        // ---- first pass: the product state of the hoisted first gates -----------------------
+        // amplitude(w) = prod_q U_q[w_q][0] over the initialised qubits, 0 where a bit of an
+        // uninitialised qubit is set; factored over the column / row halves like a diagonal stage
+        if (a.first) {
+            const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
+            double2 gs = make_double2((whi & a.zero_in) ? 0.0 : 1.0, 0.0);
+            for (int s = 0; s < a.n_init; ++s) {
+                const int2 g = s_init[s];
+                if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
+            }
+            for (uint32_t j = tid; j < nlo + nhi; j += T) {
+                const bool is_lo = j < nlo;
+                const uint32_t w = is_lo ? j : ((j - nlo) << h);
+                double2 f = (w & a.zero_in) ? make_double2(0.0, 0.0) : (is_lo ? gs : make_double2(1.0, 0.0));
+                for (int s = 0; s < a.n_init; ++s) {
+                    const int2 g = s_init[s];
+                    if (g.x < L && (g.x < h) == is_lo) f = cmul(f, mat[4 * g.y + 2 * ((w >> g.x) & 1u)]);
+                }
+                (is_lo ? tlo[j] : thi[j - nlo]) = f;
+            }
+            __syncthreads();
+            for (uint32_t l = tid; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
+            __syncthreads();
+        }
+
         // ---- stages -----------------------------------------------------------------------
-        for (int s = 0; s < a.n_stage; ++s) {
+        for (int s = a.first ? a.n_init : 0; s < a.n_stage; ++s) {
             const DevStage st = a.stages[s];
             if (st.kind == ST_DIAG) {
-                // phase(w) = tlo[low h bits] * thi[high local bits] * (terms that straddle the halves);
-                // the two tables cost 2^h + 2^(L-h) term products instead of 2^L
+                // Local bits < h are the column c of an amplitude, the rest its row r:
+                //   phase(r, c) = tlo[c] * thi[r] * X(r, c),
+                // X = the product of the terms with one bit in each half.  Each of those has ONE row
+                // bit, so X(r, c) = X(0, c) * prod_{bits a set in r} rat[a][c]: the tables cost
+                // (2^h + 2^(L-h)) * terms instead of 2^L * terms, and a thread that walks rows in
+                // Gray-code order updates X with one complex multiplication per amplitude.
                 const RTerm* tl = rt + st.t0;
                 const RTerm* th = tl + st.nLo;
                 const RTerm* tx = th + st.nHi;
-                const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
-                for (uint32_t j = tid; j < nlo + nhi; j += T) {
+                const int nrb = L - h;
+                const uint32_t nlo = 1u << h, nhi = 1u << nrb;
+                const uint32_t n_rat = st.nX ? (nlo * (uint32_t)nrb) : 0u;
+                // work items: the ratio table first (64 columns: a wavefront shares its row bit, so
+                // the term ranges are scalar reads), then the column and the row tables
+                for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
                     double fr = 1.0, fi = 0.0;
-                    if (j < nlo) {
-                        const uint32_t w = whi | j;
+                    if (j < n_rat) {
+                        const uint32_t c = j & (nlo - 1u);
+                        const uint32_t ra = __builtin_amdgcn_readfirstlane(j >> h);
+                        const uint32_t w0 = whi | c, w1 = w0 | (1u << (h + ra));
+                        const int32_t* xo = a.stages[s].xo;   // from memory: indexing the register copy would spill it
+                        double gr = 1.0, gi = 0.0;
+                        for (int k = xo[ra]; k < xo[ra + 1]; ++k) {
+                            apply_term(tx[k], w1, fr, fi);
+                            apply_term(tx[k], w0, gr, gi);
+                        }
+                        // unit-modulus factors: f1 / f0 = f1 * conj(f0)
+                        rat[j] = make_double2(fma(fr, gr, fi * gi), fma(fi, gr, -(fr * gi)));
+                    } else if (j < n_rat + nlo) {
+                        const uint32_t c = j - n_rat, w = whi | c;
                         for (int k = 0; k < st.nLo; ++k) apply_term(tl[k], w, fr, fi);
-                        tlo[j] = make_double2(fr, fi);
+                        for (int k = 0; k < st.nX; ++k) apply_term(tx[k], w, fr, fi);   // X(0, c)
+                        tlo[c] = make_double2(fr, fi);
                     } else {
-                        const uint32_t w = whi | ((j - nlo) << h);
+                        const uint32_t r = j - n_rat - nlo, w = whi | (r << h);
                         for (int k = 0; k < st.nHi; ++k) apply_term(th[k], w, fr, fi);
-                        thi[j - nlo] = make_double2(fr, fi);
+                        thi[r] = make_double2(fr, fi);
                     }
                 }
                 __syncthreads();
-                for (uint32_t l = tid; l < nloc; l += T) {
-                    const double2 f0 = tlo[l & (nlo - 1u)], f1 = thi[l >> h];
-                    double fr = fma(f0.x, f1.x, -(f0.y * f1.y)), fi = fma(f0.x, f1.y, f0.y * f1.x);
-                    const uint32_t w = whi | l;
-                    for (int k = 0; k < st.nX; ++k) apply_term(tx[k], w, fr, fi);
-                    const double2 v = state[l];
-                    state[l] = make_double2(fma(v.x, fr, -(v.y * fi)), fma(v.x, fi, v.y * fr));
+                if (st.nX == 0) {
+                    for (uint32_t l = tid; l < nloc; l += T) {
+                        const double2 f0 = tlo[l & (nlo - 1u)], f1 = thi[l >> h];
+                        const double2 v = state[l];
+                        state[l] = cmul(v, cmul(f0, f1));
+                    }
+                } else {
+                    // h == 6: lane = column; the wave owns 2^kb consecutive rows
+                    const uint32_t c = tid & 63u, wv = tid >> 6;
+                    const int kb = nrb - (a.lgT - 6);
+                    const uint32_t rpw = 1u << kb, r0 = wv << kb;
+                    double2 X = tlo[c];
+                    for (int b = kb; b < nrb; ++b)
+                        if ((r0 >> b) & 1u) X = cmul(X, rat[((uint32_t)b << h) | c]);
+                    double2 rr0 = rat[c], rr1 = rr0, rr2 = rr0, rr3 = rr0;   // ratios of the walked bits
+                    if (kb > 1) rr1 = rat[(1u << h) | c];
+                    if (kb > 2) rr2 = rat[(2u << h) | c];
+                    if (kb > 3) rr3 = rat[(3u << h) | c];
+#pragma unroll 2
+                    for (uint32_t i = 0; i < rpw; ++i) {
+                        const uint32_t g = i ^ (i >> 1);
+                        if (i > 0) {
+                            const int b = __builtin_ctz(i);              // the bit that flips between gray(i-1) and gray(i)
+                            double2 q = b == 0 ? rr0 : (b == 1 ? rr1 : (b == 2 ? rr2 : rr3));
+                            if (!((g >> b) & 1u)) q.y = -q.y;            // bit cleared: divide = multiply by the conjugate
+                            X = cmul(X, q);
+                        }
+                        const uint32_t r = r0 | g;
+                        const double2 f = cmul(X, thi[r]);
+                        const uint32_t l = (r << h) | c;
+                        state[l] = cmul(state[l], f);
+                    }
                 }
             } else if (st.kind == ST_U1) {
-                if (st.ng == 1) sweep_u1<1>(state, mat, st, nloc, tid, T);
-                else if (st.ng == 2) sweep_u1<2>(state, mat, st, nloc, tid, T);
-                else if constexpr (MAXG >= 3) sweep_u1<3>(state, mat, st, nloc, tid, T);
+                if (st.ng == 1) sweep_u1<1>(state, mat, a.mats, st, nloc, tid, T);
+                else if (st.ng == 2) sweep_u1<2>(state, mat, a.mats, st, nloc, tid, T);
+                else if constexpr (MAXG >= 3) sweep_u1<3>(state, mat, a.mats, st, nloc, tid, T);
             } else if (st.kind == ST_CX) {
                 const int vc = st.va, vt = st.vb;
                 if (vc >= L) {  // control is a chunk bit: X on the target, or nothing
@@ -311,9 +447,15 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, MAXG == 3 ? 2 : 3) sim_
             __syncthreads();
         }
         // ---- write back (amplitudes that are still known-zero are left to the next pass) ------
+        if (have_next) xbuf[(par ^ 1) * xs + tid] = xnext;
+        if (next < a.n_items)   // more features than threads: the rest without the register detour
+            for (int t = tid + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
+        __syncthreads();
         for (uint32_t l = tid; l < nloc; l += T)
             if (!(l & a.zero_out)) gpsi[chunk_phys | deposit(l, a)] = state[l];
-        __syncthreads();  // LDS is reused by the next item
+        // LDS is reused by the next item.  A bare barrier: every wave's LDS reads have returned
+        // before it issued its stores, and the stores themselves need not have landed.
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -385,8 +527,13 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
         a.n_expr = ps.n_expr;
         a.n_mat = ps.n_mat;
         a.n_term = ps.n_term;
+        a.n_prog = (int)c.prog.size();
+        a.n_consts = (int)c.consts.size();
+        a.n_params = c.n_params;
         a.L = ps.L;
         a.h = ps.h;
+        a.lgT = ps.lgT;
+        a.n_init = ps.n_init;
         a.n_qubits = n;
         a.first = ps.first ? 1 : 0;
         a.zero_in = ps.zero_in;
@@ -398,8 +545,14 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
         a.nlive = __builtin_popcount(a.live_chunks);
         if ((N >> (62 - a.nlive)) != 0) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
         a.n_items = N << a.nlive;
-        const size_t lds = ((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
-                           (size_t)16 * ((1u << ps.h) + (1u << (ps.L - ps.h)));
+        size_t lds = ((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
+                     (size_t)16 * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
+                     (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1) +
+                     (size_t)8 * ps.n_init;
+        const size_t stage_bytes = sizeof(DevExpr) * ps.n_expr + sizeof(qk_instr) * c.prog.size() + 8 * c.consts.size();
+        a.staged = lds + stage_bytes <= (size_t)160 * 1024 ? 1 : 0;
+        if (a.staged) lds += stage_bytes;
+        if (lds > (size_t)160 * 1024) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: pass tables exceed LDS");
         const int threads = 1 << ps.lgT;
         // resident workgroups per CU: LDS, and registers (MAXG = 3: 2 waves/SIMD; MAXG = 2: 3 waves/SIMD)
         const int by_regs = (ps.maxg >= 3 ? 512 : 768) / threads;

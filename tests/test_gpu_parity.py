@@ -13,7 +13,7 @@ from quake_amd import circuit as qc
 from quake_amd import featuremaps as fm
 from quake_amd import genetic
 from quake_amd.kernels import HipFidelityKernel, make_kernels, projected_quantum_kernel
-from tests._helpers import map_pairs, synth_X, two_qubit_pairs
+from tests._helpers import map_pairs, psi_from_compiled, synth_X, two_qubit_pairs
 from tests.test_circuit_ir import GATE_DICT_FULL
 
 pytestmark = pytest.mark.gpu
@@ -49,9 +49,64 @@ def test_statevectors_large_and_multipass(n, builder, repeats, N):
     circ, oops, _ = map_pairs(n, repeats)[builder]
     k = HipFidelityKernel(circ)
     got = k.statevectors(X)
-    if n > 13:
+    if n > 13 and repeats > 1:
         assert k._circuit().num_passes >= 2
     assert np.abs(got - O.statevectors(oops, n, X)).max() < TOL_PSI
+
+
+def _fresh_qubit_circuit(n):
+    """First gates on high (non-local) qubits in every flavour the planner distinguishes."""
+    x = qc.ParameterVector("x", 4)
+    c = qc.QuantumCircuit(n)
+    c.h(0); c.ry(x[0], 1)
+    c.rz(x[1], n - 1)            # diagonal gate BEFORE the first gate of the top qubit: no scalar shortcut
+    c.h(n - 1)
+    c.cx(n - 2, 0)               # control on a qubit that is still |0>
+    c.ry(x[2], n - 2)            # parametric first gate on a high qubit
+    c.sx(n - 3)                  # constant first gate on a high qubit
+    c.cz(n - 2, 2); c.cx(n - 2, 1); c.cx(n - 3, n - 2)
+    c.p(x[3], n - 3); c.rz(x[0] * x[1], n - 2)
+    for q in range(2, n - 4):
+        c.h(q)
+    for q in range(n - 4):
+        c.cx(q, q + 1); c.p(x[q % 4], q + 1); c.cx(q, q + 1)
+    c.rx(x[1], n - 2); c.h(n - 3); c.cz(0, n - 1)
+    return c                      # qubit n-4 is never touched
+
+
+@pytest.mark.parametrize("n", [9, 13, 14, 15, 17])
+def test_statevectors_fresh_high_qubits(n):
+    circ = _fresh_qubit_circuit(n)
+    X = synth_X(3, 4, "scaled", 300 + n)
+    got = HipFidelityKernel(circ).statevectors(X)
+    assert np.abs(got - psi_from_compiled(circ, X)).max() < TOL_PSI
+
+
+@pytest.mark.parametrize("n,seed", [(11, 0), (14, 1), (15, 2), (16, 3)])
+def test_statevectors_random_circuits(n, seed):
+    """Random gate soups: every stage kind, many cross-half diagonal terms, several passes."""
+    rng = np.random.default_rng(seed)
+    x = qc.ParameterVector("x", 5)
+    c = qc.QuantumCircuit(n)
+    for _ in range(12 * n):
+        g = rng.integers(0, 11)
+        q, r = (int(v) for v in rng.choice(n, size=2, replace=False))
+        a = x[int(rng.integers(0, 5))] * float(rng.uniform(0.5, 2.0))
+        if g == 0: c.h(q)
+        elif g == 1: c.sx(q)
+        elif g == 2: c.x(q)
+        elif g == 3: c.rx(a, q)
+        elif g == 4: c.ry(a, q)
+        elif g == 5: c.rz(a, q)
+        elif g == 6: c.p(a, q)
+        elif g == 7: c.cx(q, r)
+        elif g == 8: c.cz(q, r)
+        elif g == 9: c.ecr(q, r)
+        else:
+            c.cx(q, r); c.p(a, r); c.cx(q, r)
+    X = synth_X(2, 5, "scaled", 400 + n)
+    got = HipFidelityKernel(c).statevectors(X)
+    assert np.abs(got - psi_from_compiled(c, X)).max() < TOL_PSI
 
 
 @pytest.mark.parametrize("N,M", [(1, 1), (5, 3), (130, 57), (257, 129)])

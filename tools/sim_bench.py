@@ -11,14 +11,36 @@ def circuits(n):
     h = QuantumCircuit(n)
     for q in range(n): h.h(q)
     hp = fm.z_featuremap(x, n, 1)
+    def ph(qs, reps=4):       # p then h: the h is a real sweep, not a hoisted first gate
+        c = QuantumCircuit(n)
+        for _ in range(reps):
+            for q in qs: c.p(x[q], q)
+            for q in qs: c.h(q)
+        return c
+    extra = {}
+    if n >= 9:
+        extra = {"ph_low3x4": ph([0, 1, 2]), "ph_mid3x4": ph([3, 4, 5]), "ph_high3x4": ph([n - 4, n - 5, n - 6])}
     return {"h_only": h, "z_r1": hp, "zz_r1": fm.zz_featuremap(x, n, 1), "zz_r2": fm.zz_featuremap(x, n, 2),
-            "custom1_r1": fm.custom1_featuremap(x, n, 1), "custom2_r1": fm.custom2_featuremap(x, n, 1)}
+            "custom1_r1": fm.custom1_featuremap(x, n, 1), "custom2_r1": fm.custom2_featuremap(x, n, 1), **extra}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--qubits", type=int, nargs="+", default=[16, 13, 12, 10, 8])
 ap.add_argument("--gib", type=float, default=4.0, help="Psi bytes per run")
 ap.add_argument("--maps", nargs="*", default=None)
+ap.add_argument("--fill", action="store_true", help="also time a plain device fill / copy of the same size")
 a = ap.parse_args()
+if a.fill:
+    buf = torch.empty(int(a.gib * 2**30) // 8, dtype=torch.float64, device="cuda")
+    src = torch.ones_like(buf)
+    for name, fn in (("fill", lambda: buf.fill_(1.0)), ("copy", lambda: buf.copy_(src))):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(json.dumps({"op": name, "ms": round(ms, 3), "written_GBps": round(buf.numel() * 8 / ms / 1e6, 1)}), flush=True)
+    del buf, src
 for n in a.qubits:
     N = int(a.gib * 2**30 / (16 << n))
     X = torch.from_numpy(np.random.default_rng(1).uniform(-1.5, 1.5, size=(N, n))).cuda()
