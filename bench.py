@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--qubits", type=int, default=16)
     ap.add_argument("--repeats", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the 1-second MFMA ceiling probe")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = auto)")
     ap.add_argument("--check", action="store_true", help="spot-check K against the oracle after the run")
     return ap.parse_args()
@@ -71,6 +72,36 @@ def cpu_baseline(X_host, n, repeats, rows):
     }, K, Xs
 
 
+def mfma_probe(seconds=1.0):
+    """The box's FP64 MFMA ceiling right now: tools/mfma_f64_peak.bin (built by build()) keeps a
+    register-only v_mfma_f64_16x16x4 loop running for `seconds` in a child process.  Boxes of this
+    pool sustain different clocks under matrix load (2.1 - 2.4 GHz seen), so the spec-sheet peak
+    alone does not say how close the kernel is to what this GPU can do."""
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "mfma_f64_peak.bin")
+    if not os.path.exists(exe):
+        return None
+    try:
+        import subprocess
+        r = subprocess.run([exe, "--probe", str(seconds)], capture_output=True, text=True, timeout=60)
+        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception:
+        return None
+
+
+def pmc_traffic(N, n, repeats, world):
+    """HBM bytes per Gram launch from the committed PMC passes (profiles/), when this is the
+    workload they were taken on; collected per the guide (separate --pmc passes, FETCH_SIZE x2)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    w = t.get("workload", {})
+    if (w.get("rows"), w.get("qubits"), w.get("repeats"), w.get("gpus")) != (N, n, repeats, world):
+        return None
+    return t.get("gram_hbm_bytes_per_launch")
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -78,6 +109,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    probe = mfma_probe() if (world == 1 and not a.no_probe) else None   # child process, before this one touches the GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -167,7 +199,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(N, n, a.repeats, world),
                 "kernel": "qk::gram_dma_kernel<2,4,4,2,true>", "ms_per_launch_set": gram_ms,
                 "algorithmic_flops": flops_rank,
                 "mfma_flops": 0.75 * flops_rank,
@@ -180,6 +212,12 @@ def main():
             },
             "stages_ms": {"simulate": sim_ms, "gram": gram_ms},
         }
+        if probe:
+            out["roofline"]["mfma_probe_tflops"] = probe["tflops"]
+            out["roofline"]["mfma_frac_of_probe"] = 0.75 * achieved / probe["tflops"]
+            out["roofline"]["note"] += ("; mfma_probe_tflops = a register-only MFMA loop timed on this box just before "
+                                        "the run (its ceiling at the clock it sustains), mfma_frac_of_probe = hardware "
+                                        "MFMA flops / that")
         if world == 1 and not a.no_cpu_baseline:
             rows = a.cpu_rows or max(32, min(384, int(384 * (65536 / D) ** 0.5)))
             rows = min(rows, N)

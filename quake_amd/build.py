@@ -55,6 +55,19 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> 
     return LIB_PATH
 
 
+def build_probe(verbose: bool = True) -> Path:
+    """tools/mfma_f64_peak.bin: the register-only MFMA loop bench.py runs as a ceiling probe."""
+    src = PKG_DIR.parent / "tools" / "mfma_f64_peak.hip"
+    out = src.with_suffix(".bin")
+    if out.exists() and out.stat().st_mtime >= src.stat().st_mtime:
+        return out
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-Wno-unused-value", str(src), "-o", str(out)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv)
     print(LIB_PATH)

@@ -2,6 +2,8 @@
 // build: hipcc -O3 --offload-arch=gfx950 tools/mfma_f64_peak.hip -o gpurun_out/mfma_f64_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 typedef double v4d __attribute__((ext_vector_type(4)));
 template <int NACC>
 __global__ void __launch_bounds__(512, 2) k(double* out, int iters, double x, double y) {
@@ -36,7 +38,33 @@ void run(int threads, int blocks_per_cu, const char* tag) {
     }
     hipFree(out);
 }
-int main() {
+// --probe SECONDS: keep the 2-waves/SIMD loop running for about that long and print the rate of the
+// second half as one JSON line (bench.py records it as the box's MFMA ceiling at its current clock)
+static int probe(double seconds) {
+    const int threads = 512, blocks = 256, iters = 20000;
+    double* out;
+    if (hipMalloc(&out, sizeof(double) * blocks * threads) != hipSuccess) return 1;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const double flops = 2048.0 * 16 * iters * (double)blocks * (threads / 64);
+    double total_ms = 0, late_ms = 0;
+    int late_n = 0;
+    while (total_ms < seconds * 1e3) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k<16>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0, 2.0);
+        hipEventRecord(e1);
+        if (hipEventSynchronize(e1) != hipSuccess) return 1;
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        total_ms += ms;
+        if (total_ms > seconds * 5e2) { late_ms += ms; ++late_n; }
+    }
+    hipFree(out);
+    if (!late_n) return 1;
+    printf("{\"tflops\": %.3f, \"seconds\": %.3f}\n", flops * late_n / late_ms / 1e9, total_ms / 1e3);
+    return 0;
+}
+int main(int argc, char** argv) {
+    if (argc == 3 && std::string(argv[1]) == "--probe") return probe(atof(argv[2]));
     run<16>(256, 1, "1 wave/SIMD");
     run<16>(512, 1, "2 waves/SIMD");
     run<4>(512, 1, "2 waves/SIMD");
