@@ -161,6 +161,60 @@ int qk_pqk_dev(const double* rdm_x, int64_t N, const double* rdm_y, int64_t M, i
 int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t N, int n_features,
                         double gamma, double* K_host);
 
+/*
+ * Replaces: the kernel-statistics block of the GA fitness function (reference
+ * genetic_v3.py:643-660) on a symmetric K held on the device.  labels: N int32 (0 / 1) or
+ * NULL.  stats (device, QK_STATS_LEN float64) receives raw sums over the strict upper
+ * triangle i < j -- the caller forms the reference's means from them:
+ *   [0] sum K_ij            [1] sum K_ij^2
+ *   [2] sum over pairs with both labels 0     [3] ... both labels 1
+ *   [4] sum over pairs with different labels  (K symmetric: = sum of K[labels==0][:, labels==1])
+ *   [5] number of label-0 rows   [6] number of label-1 rows   [7] 0
+ * offdiagonal_mean = [0]/N^2 and offdiagonal_std = sqrt([1]/N^2 - mean^2): the reference takes
+ * both over the WHOLE N x N array np.triu(K, 1), zeros included (genetic_v3.py:659-660).
+ * Deterministic (fixed reduction tree, no atomics).  workspace: device, QK_STATS_WS float64.
+ */
+#define QK_STATS_LEN 8
+#define QK_STATS_WS (1024 * 8)
+int qk_kernel_stats_dev(const double* K_dev, int64_t N, int64_t ldk, const int32_t* labels_dev,
+                        double* stats_dev, double* workspace_dev, void* stream);
+
+/*
+ * Replaces: the noise models the reference puts on a statevector kernel matrix, applied in
+ * place to a symmetric device K (upper triangle drawn, mirrored, diagonal untouched):
+ *   QK_NOISE_GAUSSIAN  K_ij <- clip(K_ij + N(0, param), 0, 1)        (genetic_v3.py:620-627)
+ *   QK_NOISE_SHOTS     K_ij <- Binomial(param shots, K_ij) / shots   (P(0...0) estimate of the QPU runs,
+ *                      genetic_v4.py:451-459, 792: shots=8000; FidelityStatevectorKernel(shots=...))
+ * Counter-based generator (Philox4x32-10) keyed by seed and (i, j): reproducible, independent of
+ * launch geometry.  The reference draws from numpy's unseeded global stream, so parity is
+ * statistical (tests check moments), not bitwise.
+ */
+#define QK_NOISE_NONE 0
+#define QK_NOISE_GAUSSIAN 1
+#define QK_NOISE_SHOTS 2
+int qk_kernel_noise_dev(double* K_dev, int64_t N, int64_t ldk, int mode, double param, uint64_t seed,
+                        void* stream);
+
+/*
+ * Replaces: one GA generation's fitness evaluations (pygad calls fitness_func once per
+ * chromosome: reference genetic_v3.py:587-661) as ONE heterogeneous batch.  Genome g has its own
+ * circuit (any qubit / parameter count), its own feature matrix X[g] (N[g] x n_params(g), dense)
+ * and optionally labels[g] (N[g] int32).  For each genome: simulate, symmetric fidelity Gram,
+ * optional noise (seed + g), optional statistics -- all enqueued back to back on one stream with
+ * a single synchronisation at the end.  Host pointers.
+ *   K_host : count pointers (entries may be NULL: statistics only), N[g] x N[g] float64 each
+ *   stats  : NULL or count x QK_STATS_LEN float64 (needs labels)
+ */
+typedef struct qk_batch_opts {
+    int32_t noise_mode;     /* QK_NOISE_* */
+    int32_t reserved;
+    double noise_param;
+    uint64_t seed;
+} qk_batch_opts;
+int qk_evaluate_batch(int count, const qk_circuit* const* circuits, const double* const* X,
+                      const int64_t* N, const int32_t* const* labels, const qk_batch_opts* opts,
+                      double* const* K_host, double* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,15 @@ class qk_gram_job(C.Structure):
     ]
 
 
+class qk_batch_opts(C.Structure):
+    _fields_ = [("noise_mode", C.c_int32), ("reserved", C.c_int32), ("noise_param", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+STATS_LEN = 8
+STATS_WS = 1024 * 8
+NOISE_NONE, NOISE_GAUSSIAN, NOISE_SHOTS = 0, 1, 2
+
 # every symbol include/quake_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _I64 = C.c_int64
@@ -57,6 +66,10 @@ SIGNATURES = {
     "qk_rdm1_dev": (C.c_int, [_P, _I64, C.c_int, _P, _P]),
     "qk_pqk_dev": (C.c_int, [_P, _I64, _P, _I64, C.c_int, C.c_double, _P, _I64, _P]),
     "qk_projected_kernel": (C.c_int, [_P, _P, _I64, C.c_int, C.c_double, _P]),
+    "qk_kernel_stats_dev": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
+    "qk_kernel_noise_dev": (C.c_int, [_P, _I64, _I64, C.c_int, C.c_double, C.c_uint64, _P]),
+    "qk_evaluate_batch": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.POINTER(_P),
+                                    C.POINTER(qk_batch_opts), C.POINTER(_P), _P]),
 }
 
 _lib = None

@@ -11,7 +11,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = PKG_DIR / "libquake_hip.so"
-SOURCES = ["qk_api.hip", "qk_circuit.cpp", "qk_sim.hip", "qk_gram.hip", "qk_pqk.hip"]
+SOURCES = ["qk_api.hip", "qk_circuit.cpp", "qk_sim.hip", "qk_gram.hip", "qk_pqk.hip", "qk_stats.hip"]
 
 
 def hipcc() -> str:

@@ -1,8 +1,10 @@
 // C ABI glue: error reporting, circuit handles and the host-pointer entry points.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "qk_common.h"
 
@@ -200,5 +202,74 @@ extern "C" int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t
     QK_HIP(dK.alloc((size_t)N * N * sizeof(double)));
     if ((rc = qk_pqk_dev((const double*)dR.p, N, nullptr, N, n, gamma, (double*)dK.p, N, nullptr))) return rc;
     QK_HIP(hipMemcpy(K_host, dK.p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost));
+    return QK_OK;
+}
+
+extern "C" int qk_evaluate_batch(int count, const qk_circuit* const* circuits, const double* const* X, const int64_t* N,
+                                 const int32_t* const* labels, const qk_batch_opts* opts, double* const* K_host,
+                                 double* stats) {
+    if (count < 0) return fail(QK_ERR_INVALID, "qk_evaluate_batch: negative count");
+    if (count == 0) return QK_OK;
+    if (!circuits || !N || (!K_host && !stats)) return fail(QK_ERR_INVALID, "qk_evaluate_batch: null pointer");
+    const int noise = opts ? opts->noise_mode : QK_NOISE_NONE;
+    size_t x_elems = 0, k_elems = 0, l_elems = 0, psi_bytes = 0;
+    std::vector<size_t> x_off(count), k_off(count), l_off(count);
+    for (int g = 0; g < count; ++g) {
+        const qk_circuit* c = circuits[g];
+        if (!c) return fail(QK_ERR_INVALID, "qk_evaluate_batch: null circuit");
+        if (N[g] < 1) return fail(QK_ERR_INVALID, "qk_evaluate_batch: every genome needs at least one row");
+        if (c->n_params > 0 && (!X || !X[g])) return fail(QK_ERR_INVALID, "qk_evaluate_batch: X is null");
+        if (stats && (!labels || !labels[g])) return fail(QK_ERR_INVALID, "qk_evaluate_batch: statistics need labels");
+        x_off[g] = x_elems;
+        k_off[g] = k_elems;
+        l_off[g] = l_elems;
+        x_elems += (size_t)N[g] * c->n_params;
+        k_elems += (size_t)N[g] * N[g];
+        l_elems += (size_t)N[g];
+        psi_bytes = std::max(psi_bytes, ((size_t)N[g] << c->n_qubits) * 16);
+    }
+    int rc = check_device();
+    if (rc) return rc;
+    // one staging copy each for all feature rows and all labels
+    std::vector<double> hx(x_elems);
+    std::vector<int32_t> hl(stats ? l_elems : 0);
+    for (int g = 0; g < count; ++g) {
+        const size_t nx = (size_t)N[g] * circuits[g]->n_params;
+        if (nx) std::memcpy(hx.data() + x_off[g], X[g], nx * sizeof(double));
+        if (stats) std::memcpy(hl.data() + l_off[g], labels[g], (size_t)N[g] * sizeof(int32_t));
+    }
+    DevBuf dX, dL, dPsi, dK, dS, dW;
+    QK_HIP(dX.alloc(x_elems * sizeof(double)));
+    if (x_elems) QK_HIP(hipMemcpy(dX.p, hx.data(), x_elems * sizeof(double), hipMemcpyHostToDevice));
+    if (stats) {
+        QK_HIP(dL.alloc(l_elems * sizeof(int32_t)));
+        QK_HIP(hipMemcpy(dL.p, hl.data(), l_elems * sizeof(int32_t), hipMemcpyHostToDevice));
+        QK_HIP(dS.alloc((size_t)count * QK_STATS_LEN * sizeof(double)));
+        QK_HIP(dW.alloc((size_t)QK_STATS_WS * sizeof(double)));
+    }
+    QK_HIP(dPsi.alloc(psi_bytes));
+    QK_HIP(dK.alloc(k_elems * sizeof(double)));
+    // everything below is enqueued on the null stream in order: Psi and the statistics workspace
+    // are reused from genome to genome without a host synchronisation in between
+    for (int g = 0; g < count; ++g) {
+        const qk_circuit* c = circuits[g];
+        const int64_t n = N[g], D = (int64_t)1 << c->n_qubits;
+        double* Kg = (double*)dK.p + k_off[g];
+        if ((rc = qk_simulate_dev(c, (const double*)dX.p + x_off[g], n, c->n_params, dPsi.p, nullptr))) return rc;
+        if ((rc = qk_gram_dev(dPsi.p, n, nullptr, n, D, Kg, n, nullptr))) return rc;
+        if (noise != QK_NOISE_NONE &&
+            (rc = qk_kernel_noise_dev(Kg, n, n, noise, opts->noise_param, opts->seed + (uint64_t)g, nullptr)))
+            return rc;
+        if (stats && (rc = qk_kernel_stats_dev(Kg, n, n, (const int32_t*)dL.p + l_off[g],
+                                               (double*)dS.p + (size_t)g * QK_STATS_LEN, (double*)dW.p, nullptr)))
+            return rc;
+    }
+    if (K_host)
+        for (int g = 0; g < count; ++g)
+            if (K_host[g])
+                QK_HIP(hipMemcpy(K_host[g], (double*)dK.p + k_off[g], (size_t)N[g] * N[g] * sizeof(double),
+                                 hipMemcpyDeviceToHost));
+    if (stats) QK_HIP(hipMemcpy(stats, dS.p, (size_t)count * QK_STATS_LEN * sizeof(double), hipMemcpyDeviceToHost));
+    QK_HIP(hipDeviceSynchronize());
     return QK_OK;
 }

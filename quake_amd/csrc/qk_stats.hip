@@ -1,0 +1,177 @@
+// Epilogues on a symmetric kernel matrix held in HBM: the GA's kernel statistics
+// (one read of the upper triangle: 8 B per entry) and the noise models (one read-modify-write).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "qk_common.h"
+
+namespace qk {
+namespace {
+
+constexpr int kStatThreads = 256;
+constexpr int kStatMaxBlocks = 1024;   // QK_STATS_WS = kStatMaxBlocks * 8 doubles
+
+// fixed-shape tree over the block: deterministic
+__device__ __forceinline__ void block_reduce5(double v[5], double* sh /* 5 * kStatThreads */, int tid) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sh[k * kStatThreads + tid] = v[k];
+    __syncthreads();
+    for (int s = kStatThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sh[k * kStatThreads + tid] += sh[k * kStatThreads + tid + s];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = sh[k * kStatThreads];
+}
+
+// stage 1: block b owns rows b, b + gridDim, ... ; lanes walk the columns j > i (coalesced)
+__global__ void __launch_bounds__(kStatThreads) stats_partial_kernel(const double* __restrict__ K, int64_t N, int64_t ldk,
+                                                                     const int32_t* __restrict__ labels,
+                                                                     double* __restrict__ partial) {
+    __shared__ double sh[5 * kStatThreads];
+    const int tid = threadIdx.x;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int64_t i = blockIdx.x; i < N; i += gridDim.x) {
+        const int li = labels ? labels[i] : -1;
+        const double* row = K + i * ldk;
+        for (int64_t j = i + 1 + tid; j < N; j += kStatThreads) {
+            const double v = row[j];
+            acc[0] += v;
+            acc[1] = fma(v, v, acc[1]);
+            if (labels) {
+                const int lj = labels[j];
+                if (li == 0 && lj == 0) acc[2] += v;
+                else if (li == 1 && lj == 1) acc[3] += v;
+                else if ((li == 0 && lj == 1) || (li == 1 && lj == 0)) acc[4] += v;
+            }
+        }
+    }
+    block_reduce5(acc, sh, tid);
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) partial[(int64_t)blockIdx.x * 8 + k] = acc[k];
+    }
+}
+
+// stage 2: one block folds the partials in a fixed order and counts the labels
+__global__ void __launch_bounds__(kStatThreads) stats_final_kernel(const double* __restrict__ partial, int n_partial,
+                                                                   const int32_t* __restrict__ labels, int64_t N,
+                                                                   double* __restrict__ stats) {
+    __shared__ double sh[5 * kStatThreads];
+    const int tid = threadIdx.x;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int b = tid; b < n_partial; b += kStatThreads)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += partial[(int64_t)b * 8 + k];
+    block_reduce5(acc, sh, tid);
+    __syncthreads();
+    double cnt[5] = {0, 0, 0, 0, 0};
+    if (labels)
+        for (int64_t i = tid; i < N; i += kStatThreads) {
+            cnt[0] += labels[i] == 0;
+            cnt[1] += labels[i] == 1;
+        }
+    block_reduce5(cnt, sh, tid);
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) stats[k] = acc[k];
+        stats[5] = cnt[0];
+        stats[6] = cnt[1];
+        stats[7] = 0.0;
+    }
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11), counter = (i, j, t, 0), key = seed -------------------
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__global__ void __launch_bounds__(256) noise_kernel(double* __restrict__ K, int64_t N, int64_t ldk, int mode, double param,
+                                                    uint32_t k0, uint32_t k1) {
+    // 16 x 16 thread tiles over the upper triangle; (i, j) with i < j
+    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= N || j >= N || i >= j) return;
+    const double v = K[i * ldk + j];
+    double out;
+    if (mode == QK_NOISE_GAUSSIAN) {
+        const U4 r = philox((uint32_t)i, (uint32_t)j, 0u, 0u, k0, k1);
+        // two 53-bit uniforms in (0, 1]
+        const double u1 = ((double)(((uint64_t)r.x << 21) ^ (r.y >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
+        const double u2 = ((double)(((uint64_t)r.z << 21) ^ (r.w >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
+        const double g = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+        out = fmin(fmax(v + param * g, 0.0), 1.0);
+    } else {
+        const int64_t shots = (int64_t)param;
+        const double p = fmin(fmax(v, 0.0), 1.0);
+        const uint64_t thr = (uint64_t)(p * 4294967296.0);       // P(u32 < thr) = p to 2^-32
+        int64_t hits = 0;
+        for (int64_t t = 0; t * 4 < shots; ++t) {
+            const U4 r = philox((uint32_t)i, (uint32_t)j, (uint32_t)t, (uint32_t)(t >> 32), k0, k1);
+            const int64_t left = shots - t * 4;
+            hits += (uint64_t)r.x < thr;
+            if (left > 1) hits += (uint64_t)r.y < thr;
+            if (left > 2) hits += (uint64_t)r.z < thr;
+            if (left > 3) hits += (uint64_t)r.w < thr;
+        }
+        out = (double)hits / (double)shots;
+    }
+    K[i * ldk + j] = out;
+    K[j * ldk + i] = out;
+}
+
+}  // namespace
+}  // namespace qk
+
+using namespace qk;
+
+extern "C" int qk_kernel_stats_dev(const double* K, int64_t N, int64_t ldk, const int32_t* labels, double* stats,
+                                   double* workspace, void* stream) {
+    if (!K || !stats || !workspace) return fail(QK_ERR_INVALID, "qk_kernel_stats_dev: null pointer");
+    if (N < 1 || ldk < N) return fail(QK_ERR_INVALID, "qk_kernel_stats_dev: bad shape");
+    const int blocks = (int)std::min<int64_t>(N, kStatMaxBlocks);
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(blocks), dim3(kStatThreads), 0, (hipStream_t)stream, K, N, ldk, labels,
+                       workspace);
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(kStatThreads), 0, (hipStream_t)stream, workspace, blocks, labels, N,
+                       stats);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+extern "C" int qk_kernel_noise_dev(double* K, int64_t N, int64_t ldk, int mode, double param, uint64_t seed, void* stream) {
+    if (!K) return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: null pointer");
+    if (N < 1 || ldk < N) return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: bad shape");
+    if (mode == QK_NOISE_NONE) return QK_OK;
+    if (mode == QK_NOISE_GAUSSIAN) {
+        if (!(param >= 0.0)) return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: negative standard deviation");
+    } else if (mode == QK_NOISE_SHOTS) {
+        if (!(param >= 1.0) || param > 1e9) return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: shots must be in 1..1e9");
+    } else {
+        return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: unknown noise mode");
+    }
+    if (N > (int64_t)1 << 32) return fail(QK_ERR_UNSUPPORTED, "qk_kernel_noise_dev: N too large for the counter layout");
+    const int64_t tiles = (N + 15) / 16;
+    if (tiles > 65535) {
+        // grid.y limit: noise models are meant for GA-sized matrices
+        return fail(QK_ERR_UNSUPPORTED, "qk_kernel_noise_dev: N > 1048560 not supported");
+    }
+    hipLaunchKernelGGL(noise_kernel, dim3((unsigned)tiles, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, K, N, ldk, mode,
+                       param, (uint32_t)seed, (uint32_t)(seed >> 32));
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}

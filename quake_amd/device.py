@@ -117,3 +117,34 @@ def pqk(rdm_x: torch.Tensor, rdm_y: Optional[torch.Tensor], gamma: float,
     _lib.check(_lib.load().qk_pqk_dev(_dp(rdm_x.contiguous()), N, _dp(rdm_y.contiguous()) if rdm_y is not None else None,
                                       M, n, float(gamma), _dp(out), ldk, _stream_ptr()))
     return out
+
+
+def kernel_stats(K: torch.Tensor, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Raw sums of the GA's kernel statistics over the strict upper triangle of a symmetric device
+    K (see ``qk_kernel_stats_dev``): float64 [8] on the device."""
+    _require_gpu(K, labels)
+    if K.dtype != torch.float64 or K.dim() != 2 or K.shape[0] != K.shape[1] or K.stride(1) != 1:
+        raise ValueError("K must be a square float64 matrix with unit column stride")
+    if labels is not None:
+        labels = labels.to(device=K.device, dtype=torch.int32).contiguous()
+        if labels.numel() != K.shape[0]:
+            raise ValueError("labels must have one entry per row of K")
+    out = torch.empty(_lib.STATS_LEN, dtype=torch.float64, device=K.device)
+    ws = torch.empty(_lib.STATS_WS, dtype=torch.float64, device=K.device)
+    N = K.shape[0]
+    _lib.check(_lib.load().qk_kernel_stats_dev(_dp(K), N, K.stride(0) if N > 1 else N, _dp(labels), _dp(out), _dp(ws),
+                                               _stream_ptr()))
+    return out
+
+
+def kernel_noise_(K: torch.Tensor, mode: str, param: float, seed: int = 0) -> torch.Tensor:
+    """In-place noise on a symmetric device K: ``mode`` = "gaussian" (param = std, reference
+    genetic_v3.py:620-627) or "shots" (param = shots, the QPU-style P(0...0) estimate)."""
+    _require_gpu(K)
+    if K.dtype != torch.float64 or K.dim() != 2 or K.shape[0] != K.shape[1] or K.stride(1) != 1:
+        raise ValueError("K must be a square float64 matrix with unit column stride")
+    code = {"gaussian": _lib.NOISE_GAUSSIAN, "shots": _lib.NOISE_SHOTS}[mode]
+    N = K.shape[0]
+    _lib.check(_lib.load().qk_kernel_noise_dev(_dp(K), N, K.stride(0) if N > 1 else N, code, float(param),
+                                               int(seed) & (2**64 - 1), _stream_ptr()))
+    return K

@@ -208,3 +208,76 @@ def projected_quantum_kernel(fmap: QuantumCircuit, dataset: np.ndarray, gamma: f
     K = np.empty((N, N), dtype=np.float64)
     _lib.check(lib.qk_projected_kernel(circ.handle, _lib.ptr(X), N, X.shape[1], float(gamma), _lib.ptr(K)))
     return K
+
+
+def statistics_from_sums(sums: np.ndarray, N: int) -> dict:
+    """The reference's kernel statistics (genetic_v3.py:643-660) from the raw sums of
+    ``qk_kernel_stats_dev``: class-block means over the strict upper triangles, the cross-block
+    mean, and mean / std of ``np.triu(K, 1)`` over the whole N x N array (zeros included)."""
+    s, ss, s00, s11, s01, n0, n1 = (float(v) for v in sums[:7])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        m00 = np.float64(s00) / (n0 * (n0 - 1) / 2)
+        m11 = np.float64(s11) / (n1 * (n1 - 1) / 2)
+        m01 = np.float64(s01) / (n0 * n1)
+    mean = s / (N * N)
+    return {"sparsity": (m00 + m11) / 2 - m01,
+            "offdiagonal_mean": mean,
+            "offdiagonal_std": float(np.sqrt(max(ss / (N * N) - mean * mean, 0.0)))}
+
+
+def evaluate_population(feature_maps: Sequence[QuantumCircuit], x_vecs: Sequence[np.ndarray], labels=None,
+                        noise: Optional[tuple] = None, seed: int = 0, return_kernels: bool = True):
+    """Symmetric fidelity kernels of many (circuit, data) pairs in ONE library call: the GA's
+    generation (reference genetic_v3.py:587-661 runs them one by one).
+
+    feature_maps / x_vecs: one circuit and one ``[N_g, F_g]`` array per genome (sizes may differ).
+    labels: 0/1 labels (one array for all genomes, or one per genome) -> kernel statistics are
+            reduced on the device and returned as dicts (``statistics_from_sums``).
+    noise:  None, ``("gaussian", std)`` or ``("shots", shots)``, applied on the device before the
+            statistics (genome g uses ``seed + g``).
+    Returns ``(kernels or None, stats or None)``."""
+    count = len(feature_maps)
+    if len(x_vecs) != count:
+        raise ValueError("one data array per feature map")
+    if count == 0:
+        return ([] if return_kernels else None), ([] if labels is not None else None)
+    handles, xs = [], []
+    for fmap, x in zip(feature_maps, x_vecs):
+        h = _lib.CircuitHandle(fmap.compile())
+        x = _as_2d(x, "x_vec")
+        if x.shape[1] != fmap.num_parameters:
+            raise ValueError(f"x_vec and class feature map have incompatible dimensions.\n"
+                             f"x_vec has {x.shape[1]} dimensions, but feature map has {fmap.num_parameters}.")
+        if x.shape[0] < 1:
+            raise ValueError("every genome needs at least one data row")
+        handles.append(h)
+        xs.append(x)
+    lab = None
+    if labels is not None:
+        per_genome = isinstance(labels, (list, tuple)) and len(labels) == count and np.ndim(labels[0]) == 1
+        if not per_genome:
+            labels = [labels] * count
+        lab = [np.ascontiguousarray(l, dtype=np.int32) for l in labels]
+        for l, x in zip(lab, xs):
+            if l.shape != (x.shape[0],):
+                raise ValueError("labels must have one entry per data row")
+    lib = _lib.load()
+    P = C.c_void_p
+    circ_arr = (P * count)(*[h.handle for h in handles])
+    x_arr = (P * count)(*[x.ctypes.data if x.size else None for x in xs])
+    n_arr = (C.c_int64 * count)(*[x.shape[0] for x in xs])
+    lab_arr = (P * count)(*[l.ctypes.data for l in lab]) if lab is not None else None
+    Ks = [np.empty((x.shape[0], x.shape[0]), dtype=np.float64) for x in xs] if return_kernels else None
+    k_arr = (P * count)(*[k.ctypes.data for k in Ks]) if Ks is not None else None
+    sums = np.zeros((count, _lib.STATS_LEN), dtype=np.float64) if lab is not None else None
+    if Ks is None and sums is None:
+        raise ValueError("nothing to compute: return_kernels=False needs labels")
+    opts = None
+    if noise is not None:
+        mode, param = noise
+        code = {"gaussian": _lib.NOISE_GAUSSIAN, "shots": _lib.NOISE_SHOTS}[mode]
+        opts = C.pointer(_lib.qk_batch_opts(code, 0, float(param), int(seed) & (2**64 - 1)))
+    _lib.check(lib.qk_evaluate_batch(count, circ_arr, x_arr, n_arr, lab_arr, opts, k_arr,
+                                     sums.ctypes.data if sums is not None else None))
+    stats = [statistics_from_sums(sums[g], xs[g].shape[0]) for g in range(count)] if sums is not None else None
+    return Ks, stats

@@ -1,0 +1,158 @@
+"""One GA generation as one GPU batch (qk_evaluate_batch), the device-side kernel statistics and
+noise models, and the GA driver end to end on the reference's bundled data."""
+import csv
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qk_oracle as O
+from quake_amd import device as qdev
+from quake_amd import ga, genetic
+from quake_amd.kernels import HipFidelityKernel, evaluate_population, statistics_from_sums
+
+pytestmark = pytest.mark.gpu
+
+GATE_DICT = {"single_non_parametric": ["Id", "H", "X", "SX"], "single_parametric": ["RX", "RY", "RZ"],
+             "two_non_parametric": ["CX"], "two_parametric": []}
+
+
+def _ref_stats(K, y):
+    """numpy restatement of reference genetic_v3.py:643-660 (test-side, independent of the product)."""
+    k0 = K[y == 0][:, y == 0]; k1 = K[y == 1][:, y == 1]
+    a0 = k0[np.triu_indices(k0.shape[0], 1)]; a1 = k1[np.triu_indices(k1.shape[0], 1)]
+    up = np.triu(K, 1)
+    return {"sparsity": (a0.mean() + a1.mean()) / 2 - K[y == 0][:, y == 1].mean(),
+            "offdiagonal_mean": up.mean(), "offdiagonal_std": up.std()}
+
+
+def _population(count, Q, G, F, seed):
+    pop = genetic.initial_population(count, Q, G, GATE_DICT, F, rng=np.random.default_rng(seed))
+    return [genetic.to_quantum(s, GATE_DICT, F, G, Q, verbose=False, physical_qubits=tuple(range(Q))) for s in pop], pop
+
+
+def test_population_batch_matches_single_calls_and_oracle(data_cv, data_labels):
+    F = data_cv.shape[1]
+    decoded, pop = _population(7, 4, 5, F, seed=11)
+    decoded += _population(3, 6, 3, F, seed=12)[0]                 # different qubit counts in one batch
+    maps = [m for m, _ in decoded]
+    xs = [data_cv[: 40 + 5 * k, idx] for k, (_, idx) in enumerate(decoded)]     # different row counts too
+    labels = [data_labels[: x.shape[0]].astype(int) for x in xs]
+    Ks, stats = evaluate_population(maps, xs, labels=labels)
+    for k, (m, x) in enumerate(zip(maps, xs)):
+        single = HipFidelityKernel(m).evaluate(x)
+        assert np.array_equal(Ks[k], single), k                    # same kernels, same bits
+        ref = O.fidelity_kernel(O.simulate(O_ops(m), m.num_qubits, x))
+        assert np.abs(Ks[k] - ref).max() < 1e-12
+        want = _ref_stats(ref, labels[k])
+        for key in want:
+            assert abs(stats[k][key] - want[key]) < 1e-12, (k, key)
+    # statistics only (no K copied back)
+    none, stats2 = evaluate_population(maps, xs, labels=labels, return_kernels=False)
+    assert none is None and stats2 == stats
+
+
+def O_ops(circ):
+    from tests._helpers import compiled_to_oracle_ops
+    return compiled_to_oracle_ops(circ.compile())
+
+
+@pytest.mark.parametrize("N", [2, 257, 3000])
+def test_device_statistics_large(N):
+    rng = np.random.default_rng(N)
+    A = rng.uniform(0, 1, size=(N, N)); K = (A + A.T) / 2; np.fill_diagonal(K, 1.0)
+    y = rng.integers(0, 2, size=N); y[:2] = (0, 1)
+    Kd = torch.from_numpy(K).cuda()
+    sums = qdev.kernel_stats(Kd, torch.from_numpy(y).cuda()).cpu().numpy()
+    got = statistics_from_sums(sums, N)
+    want = _ref_stats(K, y)
+    for key in ("offdiagonal_mean", "offdiagonal_std"):
+        assert abs(got[key] - want[key]) < 1e-12, key
+    if N > 2:
+        assert abs(got["sparsity"] - want["sparsity"]) < 1e-12
+    assert sums[5] == (y == 0).sum() and sums[6] == (y == 1).sum()
+    # deterministic reduction: bitwise identical on a second run, and on a strided view
+    assert np.array_equal(sums, qdev.kernel_stats(Kd, torch.from_numpy(y).cuda()).cpu().numpy())
+    big = torch.zeros((N, N + 7), dtype=torch.float64, device="cuda"); big[:, :N] = Kd
+    assert np.array_equal(sums, qdev.kernel_stats(big[:, :N], torch.from_numpy(y).cuda()).cpu().numpy())
+    no_labels = qdev.kernel_stats(Kd).cpu().numpy()
+    assert np.array_equal(no_labels[:2], sums[:2]) and not no_labels[2:].any()
+
+
+def test_gaussian_noise_epilogue():
+    N, std = 600, 0.05
+    K0 = np.full((N, N), 0.5); np.fill_diagonal(K0, 1.0)
+    Kd = qdev.kernel_noise_(torch.from_numpy(K0).cuda(), "gaussian", std, seed=42).cpu().numpy()
+    assert np.array_equal(Kd, Kd.T) and (np.diag(Kd) == 1.0).all()
+    d = (Kd - K0)[np.triu_indices(N, 1)]
+    n = d.size
+    assert abs(d.mean()) < 5 * std / np.sqrt(n) and abs(d.std() / std - 1) < 0.02
+    assert abs(np.mean(d ** 4) / std ** 4 - 3) < 0.15                 # Gaussian kurtosis
+    assert abs(np.corrcoef(d[:-1], d[1:])[0, 1]) < 0.01                # neighbours uncorrelated
+    again = qdev.kernel_noise_(torch.from_numpy(K0).cuda(), "gaussian", std, seed=42).cpu().numpy()
+    other = qdev.kernel_noise_(torch.from_numpy(K0).cuda(), "gaussian", std, seed=43).cpu().numpy()
+    assert np.array_equal(Kd, again) and not np.array_equal(Kd, other)
+    # clipping to [0, 1] (reference genetic_v3.py:627)
+    edge = np.full((64, 64), 0.999); np.fill_diagonal(edge, 1.0)
+    e = qdev.kernel_noise_(torch.from_numpy(edge).cuda(), "gaussian", 0.1, seed=1).cpu().numpy()
+    assert e.min() >= 0 and e.max() <= 1 and (e == 1.0).sum() > 64
+
+
+def test_shot_noise_epilogue():
+    N, shots = 300, 8000
+    rng = np.random.default_rng(3)
+    A = rng.uniform(0, 1, size=(N, N)); K0 = np.triu(A, 1) + np.triu(A, 1).T; np.fill_diagonal(K0, 1.0)
+    K0[0, 1] = K0[1, 0] = 0.0; K0[0, 2] = K0[2, 0] = 1.0
+    Kd = qdev.kernel_noise_(torch.from_numpy(K0).cuda(), "shots", shots, seed=7).cpu().numpy()
+    assert np.array_equal(Kd, Kd.T) and (np.diag(Kd) == 1.0).all()
+    counts = Kd * shots
+    assert np.abs(counts - np.round(counts)).max() < 1e-9             # k / shots
+    assert Kd[0, 1] == 0.0 and Kd[0, 2] == 1.0
+    iu = np.triu_indices(N, 1)
+    p, k = K0[iu], Kd[iu]
+    z = (k - p) / np.sqrt(np.maximum(p * (1 - p), 1e-12) / shots)
+    ok = (p > 0.01) & (p < 0.99)
+    assert abs(z[ok].mean()) < 0.03 and abs(z[ok].std() - 1) < 0.03   # binomial mean and variance
+    # odd shot counts are honoured exactly
+    one = qdev.kernel_noise_(torch.from_numpy(K0).cuda(), "shots", 5, seed=7).cpu().numpy()
+    assert set(np.unique(np.round(one[iu] * 5)).astype(int)) <= set(range(6))
+
+
+def test_generation_fitness_matches_single_genome_path(data8, data_labels):
+    F = data8.shape[1]
+    _, pop = _population(6, 4, 6, F, seed=5)
+    fit_fun = lambda accuracy, density, depth: accuracy + 0.025 * density
+    values, stats = ga.generation_fitness(pop, data8, data_labels, GATE_DICT, F, 6, 4, fit_fun)
+    for sol, v, st in zip(pop, values, stats):
+        v1, st1 = genetic.fitness(sol, data8, data_labels, GATE_DICT, F, 6, 4, fit_fun)
+        assert abs(v - v1) < 1e-12 and st["accuracy"] == st1["accuracy"] and st["depth"] == st1["depth"]
+        for key in ("sparsity", "offdiagonal_mean", "offdiagonal_std"):
+            assert abs(st[key] - st1[key]) < 1e-12
+
+
+def test_genetic_instance_end_to_end(tmp_path, data8, data_labels):
+    """The reference's example run (examples/genetic_featuremap_v3.py:46-146) in miniature."""
+    F, Q, G = data8.shape[1], 4, 4
+    gate_dict = {"single_non_parametric": ["Id", "X", "SX"], "single_parametric": ["RZ", "RZ"],
+                 "two_non_parametric": ["ECR"], "two_parametric": []}
+    gen0 = genetic.initial_population(10, Q, G, gate_dict, F, rng=np.random.default_rng(0))
+    options = dict(num_generations=3, num_parents_mating=6, initial_population=gen0, parent_selection_type="sss",
+                   mutation_by_replacement=True, stop_criteria="saturate_250", mutation_type="random",
+                   mutation_percent_genes=1.5 * 4 / Q * 8 / G, crossover_probability=0.1, crossover_type="two_points",
+                   allow_duplicate_genes=True, keep_elitism=0,
+                   fit_fun=lambda accuracy, density, depth: accuracy + 0.025 * density, noise_std=0.044,
+                   random_seed=9)
+    run = ga.genetic_instance(genetic.get_gene_space(gate_dict, F, Q, G), data8, data_labels, None, gate_dict, F, G, Q,
+                              False, "t0", None, None, save_dir=tmp_path, verbose=False, **options)
+    run.run()
+    assert run.generations_completed == 3 and len(run.best_solutions_fitness) == 4
+    assert all(b1 >= b0 for b0, b1 in zip(run.best_solutions_fitness, run.best_solutions_fitness[1:]))
+    d = tmp_path / "t0"
+    n_lines = lambda name: len([l for l in open(d / name).read().splitlines() if l])
+    assert n_lines("genest0.csv") == run.evaluations == n_lines("accuracyt0.txt") == n_lines("fitness_values_iter_t0.csv")
+    assert n_lines("generation_idt0.txt") == run.evaluations and 10 <= run.evaluations <= 10 + 3 * 4
+    genes = [r for r in csv.reader(open(d / "genest0.csv")) if r]
+    assert all(len(r) == Q * G * 5 for r in genes)
+    run.artifacts.finish(run, data8, data_labels)
+    best = np.loadtxt(d / "best_solution.txt").astype(int)
+    assert (best == run.best_solution()[0]).all()
