@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-probe", action="store_true", help="skip the 1-second MFMA ceiling probe")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = auto)")
     ap.add_argument("--check", action="store_true", help="spot-check K against the oracle after the run")
+    ap.add_argument("--test-rows", type=int, default=-1,
+                    help="also time the test x train block of configs[4] after the timed steps (default: N/4 at N=1, 0 = off)")
     return ap.parse_args()
 
 
@@ -60,7 +62,7 @@ def cpu_baseline(X_host, n, repeats, rows):
     t1 = time.perf_counter()
     K = OC.fidelity(psi)
     t2 = time.perf_counter()
-    return {
+    out = {
         "value": rows * rows / (t2 - t0),
         "unit": "entries/s",
         "cores": 1,
@@ -69,7 +71,24 @@ def cpu_baseline(X_host, n, repeats, rows):
                   f"simulate {t1 - t0:.2f}s + pair loop {t2 - t1:.2f}s "
                   f"(pair loop alone: {rows * rows / (t2 - t1):.3e} entries/s, the large-N limit)",
         "host": f"{os.cpu_count()} logical CPUs visible; 1 thread used",
-    }, K, Xs
+    }
+    # SURVEY 8d (ii) "best CPU": the same contraction as one multithreaded zgemm on the host cores
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+        big = max(rows, min(2048, (1 << 31) // (16 << n)))          # at most 2 GiB of Psi
+        P = np.ascontiguousarray(np.tile(psi, (-(-big // rows), 1))[:big])
+        t3 = time.perf_counter()
+        G = P.conj() @ P.T
+        Kb = G.real ** 2 + G.imag ** 2
+        t4 = time.perf_counter()
+        out["best_cpu"] = {"value": big * big / (t4 - t3), "unit": "entries/s", "cores": threads,
+                           "kind": "numpy zgemm + square (all N^2 entries, Psi given)",
+                           "sample": f"{big} rows (the {rows} simulated rows tiled), {t4 - t3:.2f}s"}
+        del P, G, Kb
+    except Exception as e:   # the reported baseline is the port above; this leg is extra
+        out["best_cpu"] = {"error": repr(e)}
+    return out, K, Xs
 
 
 def mfma_probe(seconds=1.0):
@@ -174,6 +193,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # configs[4] also names 16384 test rows: the test x train cross block, outside `value`
+    test_block = None
+    T = a.test_rows if a.test_rows >= 0 else (N // 4 if world == 1 else 0)
+    if T > 0 and world == 1:
+        Xt = torch.from_numpy(rng.uniform(lo, hi, size=(T, n))).to(dev)
+        psi_t = torch.empty((T, D), dtype=torch.complex128, device=dev)
+        Kt = torch.empty((T, N), dtype=torch.float64, device=dev)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        circ.simulate(Xt, out=psi_t)
+        e[1].record()
+        qdev.gram(psi_t, psi, out=Kt)
+        e[2].record()
+        torch.cuda.synchronize()
+        t_ms = e[1].elapsed_time(e[2])
+        test_block = {"rows": T, "simulate_ms": e[0].elapsed_time(e[1]), "gram_ms": t_ms,
+                      "entries_per_s": T * N / ((e[0].elapsed_time(e[2])) * 1e-3),
+                      "gram_tflops_algorithmic": 8.0 * D * T * N / (t_ms * 1e-3) / 1e12}
+        del psi_t, Kt, Xt
+
     gram_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(ev["gram_begin"], ev["gram_end"])])) if a.steps else 0.0
     sim_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(ev["sim_begin"], ev["sim_end"])])) if a.steps else 0.0
     entries_rank = sharded.computed_entries(rank, world, N)
@@ -212,6 +251,8 @@ def main():
             },
             "stages_ms": {"simulate": sim_ms, "gram": gram_ms},
         }
+        if test_block:
+            out["test_block"] = test_block
         if probe:
             out["roofline"]["mfma_probe_tflops"] = probe["tflops"]
             out["roofline"]["mfma_frac_of_probe"] = 0.75 * achieved / probe["tflops"]
