@@ -372,9 +372,13 @@ def genetic_instance(gene_space, data_cv, data_labels, backend, gate_dict, nb_fe
                      verbose: bool = True, **kwargs) -> GeneticRun:
     """Same positional signature as reference ``genetic_instance`` (genetic_v3.py:451-533); returns
     a :class:`GeneticRun` where the reference returns ``pygad.GA``.  ``backend`` is accepted and
-    unused (as in the reference's statevector path); ``basis_gates`` only matters to a
-    caller-supplied ``depth_fn`` (the Qiskit transpiler is not part of this build: the default
-    depth is that of the circuit as decoded)."""
+    unused (as in the reference's statevector path).  ``depth`` comes from
+    ``transpile.transpiled_depth(fmap, coupling_map, basis_gates)``, the native stand-in for
+    ``transpile(...).depth()`` (reference :652-654), unless ``depth_fn`` is given."""
+    from .transpile import transpiled_depth
+
+    if depth_fn is None:
+        depth_fn = lambda fmap: transpiled_depth(fmap, coupling_map, basis_gates)
     start_time = time.time()
     art = GeneticArtifacts(save_dir, suffix) if save_dir is not None else None
     counter = {"seed": int(kwargs.get("random_seed") or 0)}

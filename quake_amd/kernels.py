@@ -66,8 +66,10 @@ class HipFidelityKernel:
                  training_parameters: Optional[Sequence[Parameter]] = None,
                  parameter_values: Optional[Sequence[float]] = None,
                  shots=None, cache_size=None, auto_clear_cache: bool = True):
-        if shots is not None:
-            raise NotImplementedError("finite-shot fidelity estimation is not implemented")
+        if shots is not None and int(shots) < 1:
+            raise ValueError("shots must be a positive integer")
+        self._shots = int(shots) if shots is not None else None
+        self._shot_calls = 0
         self._feature_map = feature_map
         self._training_parameters = list(training_parameters) if training_parameters is not None else []
         self._enforce_psd = bool(enforce_psd)
@@ -143,6 +145,14 @@ class HipFidelityKernel:
 
         ``y_vec is None`` gives the symmetric matrix with an exact unit diagonal."""
         x, y = self._validate(x_vec, y_vec)
+        if self._shots is not None:
+            # FidelityStatevectorKernel(shots=...): each entry becomes Binomial(shots, K_ij) / shots.
+            # Sampled on the device (qk_kernel_noise_dev) for the symmetric matrix.
+            if y is not None:
+                raise NotImplementedError("finite-shot sampling is implemented for the symmetric (y_vec=None) matrix")
+            self._shot_calls += 1
+            Ks, _ = evaluate_population([self._bound], [x], noise=("shots", self._shots), seed=self._shot_calls)
+            return Ks[0]
         lib = _lib.load()
         circ = self._circuit()
         n, m = x.shape[0], (x.shape[0] if y is None else y.shape[0])

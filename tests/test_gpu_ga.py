@@ -156,3 +156,46 @@ def test_genetic_instance_end_to_end(tmp_path, data8, data_labels):
     run.artifacts.finish(run, data8, data_labels)
     best = np.loadtxt(d / "best_solution.txt").astype(int)
     assert (best == run.best_solution()[0]).all()
+
+
+def test_finite_shot_kernel_object(data8):
+    """FidelityStatevectorKernel(shots=...) semantics: Binomial(shots, K) / shots per entry."""
+    from quake_amd import featuremaps as fm
+    from quake_amd.circuit import ParameterVector
+    X = np.asarray(data8[:40], dtype=np.float64) * 3 - 1.5
+    circ = fm.zz_featuremap(ParameterVector("x", 8), 8, 1)
+    exact = HipFidelityKernel(circ).evaluate(X)
+    k = HipFidelityKernel(circ, shots=4000)
+    s1, s2 = k.evaluate(X), k.evaluate(X)
+    assert np.array_equal(s1, s1.T) and (np.diag(s1) == 1).all() and not np.array_equal(s1, s2)   # fresh draws per call
+    assert np.abs(s1 * 4000 - np.round(s1 * 4000)).max() < 1e-9
+    iu = np.triu_indices(40, 1)
+    z = (s1[iu] - exact[iu]) / np.sqrt(np.maximum(exact[iu] * (1 - exact[iu]), 1e-9) / 4000)
+    assert np.abs(z).max() < 6 and abs(z.std() - 1) < 0.25
+
+
+def test_kernel_alignment_lowers_the_svc_loss():
+    """align=True maps + SPSA on the SVC dual objective (reference qsvm_tester.py:236-280)."""
+    from quake_amd import alignment, featuremaps as fm
+    from quake_amd.circuit import ParameterVector
+    from quake_amd.kernels import make_kernels
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1.2, 1.2, size=(80, 2))
+    y = (X[:, 0] * X[:, 1] > 0).astype(float)
+    fmap = fm.z_featuremap(ParameterVector("x", 2), 2, 1, align=True)
+    (kernel,) = make_kernels([fmap])
+    assert len(kernel.training_parameters) == 2 and np.all(kernel.parameter_values == 0)
+    # the loss is the SVC dual objective of K(theta)
+    from sklearn.svm import SVC
+    K = kernel.evaluate(X)
+    svc = SVC(kernel="precomputed", C=1.0).fit(K, y)
+    a = np.zeros(80); a[svc.support_] = svc.dual_coef_[0]
+    assert abs(alignment.svc_loss(K, y, 1.0) - (np.abs(a).sum() - 0.5 * a @ K @ a)) < 1e-12
+    aligned, (result, history) = alignment.align_kernel(kernel, X, y, 1.0, maxiter=20, seed=1)
+    assert len(history) == 20 and result["optimizer_evals"] == 2 * 25 + 2 * 20
+    assert aligned.training_parameters == kernel.training_parameters and np.any(aligned.parameter_values != 0)
+    assert result["optimal_value"] < result["initial_value"]
+    # the aligned kernel is an ordinary kernel object: same numbers as the oracle at the found theta
+    bound = fmap.assign_parameters(dict(zip(kernel.training_parameters, aligned.parameter_values)))
+    ref = O.fidelity_kernel(O.simulate(O_ops(bound), 2, X))
+    assert np.abs(aligned.evaluate(X) - ref).max() < 1e-12
