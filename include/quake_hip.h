@@ -147,6 +147,18 @@ int qk_evaluate(const qk_circuit* c, const double* X, int64_t N,
 int qk_rdm1_dev(const void* psi_dev, int64_t N, int n_qubits, double* rdm_dev, void* stream);
 
 /*
+ * Replaces: the same two steps of projected_quantum_kernel (reference genetic_v3.py:795-803:
+ * assign_parameters -> DensityMatrix -> partial_trace per qubit) without ever writing the
+ * statevectors: when the circuit runs as one LDS-resident pass (qk_simulate_rdm1_is_fused: n <= 12
+ * qubits, or 13 where the planner keeps 13 local), the reduced density matrices are reduced from LDS
+ * at the end of the simulation.  Otherwise psi_ws_dev (N x 2^n complex128 workspace) is required and
+ * the call is qk_simulate_dev + qk_rdm1_dev.
+ */
+int qk_simulate_rdm1_is_fused(const qk_circuit* c);
+int qk_simulate_rdm1_dev(const qk_circuit* c, const double* X_dev, int64_t N, int64_t ldx,
+                         double* rdm_dev, void* psi_ws_dev, void* stream);
+
+/*
  * Replaces: the pair loop of projected_quantum_kernel (reference genetic_v3.py:793-805):
  * K[i][j] = exp(-gamma * sum_q ||rho_i^q - rho_j^q||_F)  (un-squared Frobenius norm).
  * rdm_y == NULL: symmetric N x N with exact unit diagonal.

@@ -25,7 +25,7 @@ def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "qk_common.h", INCLUDE / "quake_hip.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "qk_common.h", CSRC / "qk_rdm.h", INCLUDE / "quake_hip.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "qk_common.h"
+#include "qk_rdm.h"
 
 namespace qk {
 
@@ -53,63 +54,38 @@ __global__ void __launch_bounds__(RDM_THREADS) rdm1_kernel(const double2* __rest
 }
 
 // n <= 13: the sample's statevector is staged in LDS once (one coalesced HBM read, the algorithmic
-// minimum), then ONE sweep updates all qubits: |psi_b|^2 goes to rho00 or rho11 of every qubit, and
-// for the qubits whose bit is clear in b the partner psi_{b | 1<<q} is read from LDS for rho01.
-constexpr int RDM_MAXQ = 13;
+// minimum), then rdm1_from_lds (qk_rdm.h) reduces every qubit in one sweep.
 __global__ void __launch_bounds__(RDM_THREADS) rdm1_lds_kernel(const double2* __restrict__ psi, int64_t N, int n,
                                                                double* __restrict__ rdm) {
-    extern __shared__ double2 st[];                 // 2^n amplitudes, then 4 * n * waves partial sums
+    extern __shared__ double2 st[];                 // 2^n amplitudes, then RDM_SLOTS * waves partial sums
     const uint32_t D = 1u << n;
     double* red = (double*)(st + D);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int WAVES = RDM_THREADS / 64;
+    const int tid = threadIdx.x;
     for (int64_t s = blockIdx.x; s < N; s += gridDim.x) {
         const double2* p = psi + (s << n);
         for (uint32_t b = tid; b < D; b += RDM_THREADS) st[b] = p[b];
         __syncthreads();
-        double r00[RDM_MAXQ], r11[RDM_MAXQ], xr[RDM_MAXQ], xi[RDM_MAXQ];
-#pragma unroll
-        for (int q = 0; q < RDM_MAXQ; ++q) { r00[q] = 0; r11[q] = 0; xr[q] = 0; xi[q] = 0; }
-        for (uint32_t b = tid; b < D; b += RDM_THREADS) {
-            const double2 a0 = st[b];
-            const double pr = fma(a0.x, a0.x, a0.y * a0.y);
-#pragma unroll
-            for (int q = 0; q < RDM_MAXQ; ++q) {
-                if (q < n) {
-                    if ((b >> q) & 1u) {
-                        r11[q] += pr;
-                    } else {
-                        const double2 a1 = st[b | (1u << q)];
-                        r00[q] += pr;
-                        xr[q] = fma(a0.x, a1.x, fma(a0.y, a1.y, xr[q]));      // a0 * conj(a1)
-                        xi[q] = fma(a0.y, a1.x, fma(-a0.x, a1.y, xi[q]));
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < RDM_MAXQ; ++q) {
-            if (q < n) {
-                double v[4] = {r00[q], r11[q], xr[q], xi[q]};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    double x = v[k];
-                    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-                    if (lane == 0) red[(q * 4 + k) * WAVES + wave] = x;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < 4 * n) {
-            double x = 0;
-            for (int w = 0; w < WAVES; ++w) x += red[tid * WAVES + w];
-            rdm[s * n * 4 + tid] = x;
-        }
-        __syncthreads();
+        rdm1_from_lds(st, n, red, rdm + s * n * 4, tid, RDM_THREADS);
     }
 }
 
 constexpr int PT = 64;  // pqk tile side: 256 threads x (4 x 4) entries
+
+// sqrt for x in [0, 16]: the pairwise kernel is bound by one square root per (pair, qubit), and the
+// library routine spends half its instructions on range scaling this input never needs.  Hardware
+// reciprocal-square-root seed (~26 bits) + two Goldschmidt steps: error below 1 ulp.
+__device__ __forceinline__ double sqrt_small(double x) {
+    const double y = __builtin_amdgcn_rsq(x);        // +inf for x == 0, handled by the select below
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    const double d = fma(-g, g, x);                  // residual correction: g += (x - g^2) * h
+    g = fma(d, h, g);
+    return x < 1e-280 ? 0.0 : g;
+}
 
 // LDS image per side: [qubit][component][row] (rows contiguous): the 16 lanes that differ in their
 // column read 16 consecutive doubles (conflict free), the lanes that share a row read one address
@@ -162,7 +138,7 @@ __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx,
                 const double d0 = a[r][0] - b[c][0], d1 = a[r][1] - b[c][1];
                 const double dr = a[r][2] - b[c][2], di = a[r][3] - b[c][3];
                 // Frobenius norm of the 2x2 difference: |d00|^2 + |d11|^2 + 2 |d01|^2
-                acc[r][c] += sqrt(fma(d0, d0, fma(d1, d1, 2.0 * fma(dr, dr, di * di))));
+                acc[r][c] += sqrt_small(fma(d0, d0, fma(d1, d1, 2.0 * fma(dr, dr, di * di))));
             }
     }
     const bool diag_tile = sym && ti == tj;
@@ -193,7 +169,7 @@ extern "C" int qk_rdm1_dev(const void* psi_dev, int64_t N, int n_qubits, double*
     if (N < 0 || N > 0x7fffffffLL) return fail(QK_ERR_INVALID, "qk_rdm1_dev: N out of range");
     if (N == 0) return QK_OK;
     if (n_qubits <= RDM_MAXQ) {
-        const size_t lds = ((size_t)16 << n_qubits) + (size_t)4 * n_qubits * (RDM_THREADS / 64) * sizeof(double);
+        const size_t lds = ((size_t)16 << n_qubits) + (size_t)RDM_SLOTS * (RDM_THREADS / 64) * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) {
             QK_HIP(hipFuncSetAttribute((const void*)rdm1_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

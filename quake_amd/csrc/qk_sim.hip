@@ -16,13 +16,15 @@
 #include <cstdlib>
 
 #include "qk_common.h"
+#include "qk_rdm.h"
 
 namespace qk {
 
 struct SimArgs {
     const double* X;
     int64_t ldx;
-    double2* psi;
+    double2* psi;   // may be null in fused-RDM mode (the statevectors are never written)
+    double* rdm;    // fused mode: N x n x 4 reduced density matrices, computed from LDS (single chunk per sample)
     int64_t D;  // amplitudes per sample
     const DevStage* stages;
     const DevTerm* terms;
@@ -32,6 +34,7 @@ struct SimArgs {
     const double* consts;
     int n_stage, n_expr, n_mat, n_term;
     int n_prog, n_consts, n_params, staged;   // staged: exprs / prog / consts are copied to LDS
+    int red_off;                               // fused-RDM scratch: offset in doubles from the end of xbuf
     int L, h, lgT, n_qubits, first;
     uint32_t zero_in, zero_out;  // virtual-bit masks of still-|0> qubits (see Pass)
     int n_init;                  // first pass: leading ST_INIT stages (hoisted first gates)
@@ -204,8 +207,10 @@ __device__ __forceinline__ void run_angle_programs(ExprPtr exprs, ProgPtr prog, 
 }
 
 // MAXG = 3: 512 threads, up to 256 VGPRs (radix-8 sweeps); MAXG = 2: 256 threads, up to 168 VGPRs, 3 waves/SIMD
-template <int MAXG>
-__global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, MAXG == 3 ? 2 : 3) sim_pass_kernel(SimArgs a) {
+// RDM = true: the fused simulate + reduced-density-matrix variant (qk_simulate_rdm1_dev); the reduction
+// holds 16 amplitudes per thread, so it gets the 256-VGPR budget (2 waves/SIMD) of its own instantiation.
+template <int MAXG, bool RDM>
+__global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 : 3) sim_pass_kernel(SimArgs a) {
     extern __shared__ double2 lds[];
     const int L = a.L, h = a.h;
     const uint32_t nloc = 1u << L;
@@ -221,6 +226,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, MAXG == 3 ? 2 : 3) sim_
     qk_instr* s_prog = (qk_instr*)(s_expr + a.n_expr);
     double* s_const = (double*)(s_prog + a.n_prog);
     int2* s_init = (int2*)(s_const + a.n_consts);           // (virtual bit, matrix) of the hoisted first gates
+    double* s_red = (double*)(xbuf + 2 * xs) + a.red_off;   // fused-RDM partial sums
     const int tid = threadIdx.x;
     const int T = blockDim.x;
 
@@ -451,8 +457,10 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, MAXG == 3 ? 2 : 3) sim_
         if (next < a.n_items)   // more features than threads: the rest without the register detour
             for (int t = tid + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
         __syncthreads();
-        for (uint32_t l = tid; l < nloc; l += T)
-            if (!(l & a.zero_out)) gpsi[chunk_phys | deposit(l, a)] = state[l];
+        if constexpr (RDM) rdm1_from_lds(state, L, s_red, a.rdm + sample * (L * 4), tid, T);
+        if (!RDM || a.psi)
+            for (uint32_t l = tid; l < nloc; l += T)
+                if (!(l & a.zero_out)) gpsi[chunk_phys | deposit(l, a)] = state[l];
         // LDS is reused by the next item.  A bare barrier: every wave's LDS reads have returned
         // before it issued its stores, and the stores themselves need not have landed.
         __builtin_amdgcn_s_barrier();
@@ -493,12 +501,10 @@ void free_circuit_device(qk_circuit& c) {
 
 }  // namespace qk
 
-extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx,
-                               void* psi_dev, void* stream) {
-    using namespace qk;
-    if (!cc || !psi_dev) return fail(QK_ERR_INVALID, "qk_simulate_dev: null circuit or output");
-    if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate_dev: negative N");
-    if (N == 0) return QK_OK;
+namespace qk {
+// psi and / or rdm: rdm != null asks for the fused mode (one pass, one chunk per sample)
+static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx, void* psi_dev, double* rdm_dev,
+                         void* stream) {
     qk_circuit& c = *const_cast<qk_circuit*>(cc);
     if (c.n_params > 0 && (!X_dev || ldx < c.n_params))
         return fail(QK_ERR_INVALID, "qk_simulate_dev: X is null or its row stride is smaller than the parameter count");
@@ -507,8 +513,10 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
     const int n = c.n_qubits;
     static bool attr_set = false;
     if (!attr_set) {
-        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     for (const Pass& ps : c.passes) {
@@ -516,6 +524,7 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
         a.X = X_dev;
         a.ldx = ldx;
         a.psi = (double2*)psi_dev;
+        a.rdm = rdm_dev;
         a.D = (int64_t)1 << n;
         a.stages = c.d_stages + ps.stage_off;
         a.terms = c.d_terms + ps.term_off;
@@ -552,18 +561,54 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
         const size_t stage_bytes = sizeof(DevExpr) * ps.n_expr + sizeof(qk_instr) * c.prog.size() + 8 * c.consts.size();
         a.staged = lds + stage_bytes <= (size_t)160 * 1024 ? 1 : 0;
         if (a.staged) lds += stage_bytes;
+        if (rdm_dev) {
+            a.red_off = (int)((lds - (((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
+                                      (size_t)16 * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
+                                      (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1))) / 8);
+            lds += (size_t)8 * RDM_SLOTS * ((1 << ps.lgT) / 64);
+        }
         if (lds > (size_t)160 * 1024) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: pass tables exceed LDS");
         const int threads = 1 << ps.lgT;
         // resident workgroups per CU: LDS, and registers (MAXG = 3: 2 waves/SIMD; MAXG = 2: 3 waves/SIMD)
-        const int by_regs = (ps.maxg >= 3 ? 512 : 768) / threads;
+        const int by_regs = ((ps.maxg >= 3 || rdm_dev) ? 512 : 768) / threads;
         int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)by_regs);
         per_cu = std::max(1, std::min(per_cu, 16));
         const int64_t nblocks = std::min<int64_t>(a.n_items, (int64_t)256 * per_cu);
-        if (ps.maxg >= 3)
-            hipLaunchKernelGGL(sim_pass_kernel<3>, dim3((unsigned)nblocks), dim3(threads), lds, (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL(sim_pass_kernel<2>, dim3((unsigned)nblocks), dim3(threads), lds, (hipStream_t)stream, a);
+        const dim3 grid((unsigned)nblocks), block(threads);
+        if (rdm_dev && ps.maxg >= 3) hipLaunchKernelGGL((sim_pass_kernel<3, true>), grid, block, lds, (hipStream_t)stream, a);
+        else if (rdm_dev) hipLaunchKernelGGL((sim_pass_kernel<2, true>), grid, block, lds, (hipStream_t)stream, a);
+        else if (ps.maxg >= 3) hipLaunchKernelGGL((sim_pass_kernel<3, false>), grid, block, lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((sim_pass_kernel<2, false>), grid, block, lds, (hipStream_t)stream, a);
         QK_HIP(hipGetLastError());
     }
     return QK_OK;
+}
+}  // namespace qk
+
+extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx,
+                               void* psi_dev, void* stream) {
+    using namespace qk;
+    if (!cc || !psi_dev) return fail(QK_ERR_INVALID, "qk_simulate_dev: null circuit or output");
+    if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate_dev: negative N");
+    if (N == 0) return QK_OK;
+    return simulate_impl(cc, X_dev, N, ldx, psi_dev, nullptr, stream);
+}
+
+extern "C" int qk_simulate_rdm1_dev(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx, double* rdm_dev,
+                                    void* psi_ws_dev, void* stream) {
+    using namespace qk;
+    if (!cc || !rdm_dev) return fail(QK_ERR_INVALID, "qk_simulate_rdm1_dev: null circuit or output");
+    if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate_rdm1_dev: negative N");
+    if (N == 0) return QK_OK;
+    if (qk_simulate_rdm1_is_fused(cc)) return simulate_impl(cc, X_dev, N, ldx, nullptr, rdm_dev, stream);
+    if (!psi_ws_dev)
+        return fail(QK_ERR_INVALID, "qk_simulate_rdm1_dev: this circuit needs a statevector workspace (not fused)");
+    const int rc = simulate_impl(cc, X_dev, N, ldx, psi_ws_dev, nullptr, stream);
+    if (rc) return rc;
+    return qk_rdm1_dev(psi_ws_dev, N, cc->n_qubits, rdm_dev, stream);
+}
+
+extern "C" int qk_simulate_rdm1_is_fused(const qk_circuit* c) {
+    // the whole statevector of a sample is one LDS-resident chunk of a single pass
+    return c && c->passes.size() == 1 && c->passes[0].L == c->n_qubits && c->n_qubits <= qk::RDM_MAXQ ? 1 : 0;
 }

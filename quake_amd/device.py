@@ -59,6 +59,24 @@ class DeviceCircuit:
         return out
 
 
+def simulate_rdm1(circuit: "DeviceCircuit", X: torch.Tensor) -> torch.Tensor:
+    """Per-qubit reduced density matrices of the encoded states, float64 [N, n, 4], without writing
+    the statevectors when the circuit fits one LDS-resident pass (``qk_simulate_rdm1_dev``)."""
+    _require_gpu(X)
+    lib = _lib.load()
+    if X.dtype != torch.float64 or X.dim() != 2 or X.shape[1] != circuit.n_params or (X.numel() and X.stride(1) != 1):
+        raise ValueError("X must be float64 [N, n_params] with unit column stride")
+    N, n = X.shape[0], circuit.n_qubits
+    out = torch.empty((N, n, 4), dtype=torch.float64, device=X.device)
+    ws = None
+    if not lib.qk_simulate_rdm1_is_fused(circuit.handle.handle):
+        ws = torch.empty((N, 1 << n), dtype=torch.complex128, device=X.device)
+    ldx = X.stride(0) if (N > 1 and X.shape[1]) else max(X.shape[1], 1)
+    _lib.check(lib.qk_simulate_rdm1_dev(circuit.handle.handle, _dp(X) if X.numel() else None, N, ldx, _dp(out), _dp(ws),
+                                        _stream_ptr()))
+    return out
+
+
 def gram_jobs(jobs: Sequence[dict], D: int) -> None:
     """Run several block jobs in one launch.  Each job: dict(A=, B=, K=, KT=None, symmetric=False);
     A, B complex128 [rows, D] contiguous; K (and KT) float64 2-D views with unit column stride."""

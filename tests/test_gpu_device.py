@@ -75,3 +75,22 @@ def test_multi_job_launch_matches_plan():
         assert np.abs(got[t.a0 - g0:t.a1 - g0, t.b0:t.b1] - Kref[t.a0:t.a1, t.b0:t.b1]).max() < 1e-12
     for t, buf in sends:
         assert np.abs(buf.cpu().numpy() - Kref[t.b0:t.b1, t.a0:t.a1]).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,N,fused", [(1, 5, True), (3, 70, True), (9, 33, True), (12, 9, True), (14, 4, False)])
+def test_fused_simulate_rdm1(n, N, fused):
+    """qk_simulate_rdm1_dev: the RDMs come straight from the LDS-resident state (no Psi in HBM) when
+    the circuit is one chunk per sample; otherwise through the workspace path.  Same numbers."""
+    import torch
+    from quake_amd import _lib, device as qdev, featuremaps as fm
+    from quake_amd.circuit import ParameterVector
+    X = np.random.default_rng(40 + n).uniform(-1.5, 1.5, size=(N, n))
+    circ = qdev.DeviceCircuit(fm.zz_featuremap(ParameterVector("x", n), n, 2))
+    assert bool(_lib.load().qk_simulate_rdm1_is_fused(circ.handle.handle)) == fused
+    Xd = torch.from_numpy(X).cuda()
+    got = qdev.simulate_rdm1(circ, Xd).cpu().numpy()
+    r = O.rdm1(O.statevectors(O.zz_featuremap(n, 2), n, X), n)
+    want = np.stack([r[..., 0, 0].real, r[..., 1, 1].real, r[..., 0, 1].real, r[..., 0, 1].imag], axis=-1)
+    assert np.abs(got - want).max() < 1e-13
+    two_step = qdev.rdm1(circ.simulate(Xd), n).cpu().numpy()
+    assert np.abs(got - two_step).max() < 1e-15
