@@ -46,7 +46,6 @@ struct GramArgs {
     GramJobDev job[QK_GRAM_MAX_JOBS];
     int n_jobs;
     int64_t D;  // amplitudes per row
-    int dbg;    // diagnostics only (tools/gram_ab.py): 1 = no global loads / LDS writes, 2 = also no barrier
 };
 
 // Which block tile does this workgroup compute?  Returns false for padding workgroups.
@@ -219,12 +218,10 @@ gram_kernel(GramArgs args) {
         for (int64_t kt = 0; kt < ktiles; ++kt) {
             const int cur = (int)(kt & 1);
             const int64_t off = min(kt + 1, ktiles - 1) * BK;  // last tile re-reads itself (branch-free)
-            if (args.dbg == 0) {
 #pragma unroll
             for (int p = 0; p < C::PA; ++p) pa[p] = gA[p][off];
 #pragma unroll
             for (int p = 0; p < C::PB; ++p) pb[p] = gB[p][off];
-            }
             __builtin_amdgcn_sched_barrier(0);  // keep the loads at the top of the k-tile
             const v2d* S = smem + cur * C::BUF;
             v2d* Sn = smem + (cur ^ 1) * C::BUF;
@@ -252,13 +249,11 @@ gram_kernel(GramArgs args) {
 #pragma unroll
                     for (int n = 0; n < TN; ++n) b[n] = S[(kk + 1) * 4 * C::LDB + b_off + n * 16];
                 } else {
-                    if (args.dbg == 0) {
 #pragma unroll
                     for (int p = 0; p < C::PA; ++p) Sn[sA[p]] = pa[p];
 #pragma unroll
                     for (int p = 0; p < C::PB; ++p) Sn[sB[p]] = pb[p];
-                    }
-                    if (args.dbg < 2) __syncthreads();
+                    __syncthreads();
 #pragma unroll
                     for (int m = 0; m < TM; ++m) a[m] = Sn[a_off + m * 16];
 #pragma unroll
@@ -455,7 +450,7 @@ gram_dma_kernel(GramArgs args) {
                     for (int n = 0; n < TN; ++n)
                         acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (args.dbg == 0 && kk < 3) issue_dma(cur ^ 1, noff, kk);
+                if (kk < 3) issue_dma(cur ^ 1, noff, kk);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
@@ -469,7 +464,7 @@ gram_dma_kernel(GramArgs args) {
 #pragma unroll
                     for (int n = 0; n < TN; ++n) b[n] = S[b_row + n * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
                 } else {
-                    if (args.dbg < 2) __syncthreads();
+                    __syncthreads();
 #pragma unroll
                     for (int m = 0; m < TM; ++m) a[m] = Sn[a_row + m * 256 + xs[0]];
 #pragma unroll
@@ -482,7 +477,7 @@ gram_dma_kernel(GramArgs args) {
                     for (int n = 0; n < TN; ++n)
                         acc[2][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[m], db[n], acc[2][m][n], 0, 0, 0);
             } else {
-                if (args.dbg == 0 && kk < 3) issue_dma(cur ^ 1, noff, kk);
+                if (kk < 3) issue_dma(cur ^ 1, noff, kk);
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -573,7 +568,6 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 4;  // dma3m_128x128_w8: fastest measured (tools/gram_ab.py); variant 0 serves D < 16
 
 static int g_variant = -1;
-static int g_dbg = 0;
 static bool g_attr_set[kNumVariants] = {false};
 
 static int pick_variant() {
@@ -599,7 +593,6 @@ extern "C" int qk_gram_set_variant(const char* name) {
     return fail(QK_ERR_INVALID, "qk_gram_set_variant: unknown variant");
 }
 
-extern "C" int qk_gram_set_debug(int v) { qk::g_dbg = v; return 0; }
 
 extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
     using namespace qk;
@@ -612,7 +605,6 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
     GramArgs args;
     std::memset(&args, 0, sizeof(args));
     args.D = D;
-    args.dbg = g_dbg;
     int64_t blocks = 0;
     int nj = 0;
     for (int k = 0; k < n_jobs; ++k) {

@@ -11,14 +11,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=16384)
 ap.add_argument("--qubits", type=int, default=16)
 ap.add_argument("--rounds", type=int, default=3)
-ap.add_argument("--dbg", type=int, default=0)
 ap.add_argument("--cross", action="store_true", help="non-symmetric N x N block instead of the symmetric one")
 ap.add_argument("variants", nargs="*")
 a = ap.parse_args()
 lib = _lib.load()
 lib.qk_gram_set_variant.argtypes = [C.c_char_p]
 lib.qk_gram_set_variant.restype = C.c_int
-lib.qk_gram_set_debug(a.dbg)
 N, n = a.rows, a.qubits
 D = 1 << n
 X = torch.from_numpy(np.random.default_rng(1005).uniform(-1.5, 1.5, size=(N, n))).cuda()
