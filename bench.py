@@ -27,6 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 (f32 in, f32 acc)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz)
 
 
@@ -42,6 +43,8 @@ def parse():
     ap.add_argument("--no-probe", action="store_true", help="skip the 1-second MFMA ceiling probe")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = auto)")
     ap.add_argument("--check", action="store_true", help="spot-check K against the oracle after the run")
+    ap.add_argument("--precision", choices=["double", "single"], default="double",
+                    help="single = complex64 statevectors + FP32-MFMA Gram stage (optional mode, 1e-5 tolerance)")
     ap.add_argument("--test-rows", type=int, default=-1,
                     help="also time the test x train block of configs[4] after the timed steps (default: N/4 at N=1, 0 = off)")
     return ap.parse_args()
@@ -150,7 +153,8 @@ def main():
     X = torch.from_numpy(X_host[r0:r1].copy()).to(dev)
 
     circ = qdev.DeviceCircuit(fm.zz_featuremap(ParameterVector("x", n), n, a.repeats))
-    psi = torch.empty((N, D), dtype=torch.complex128, device=dev)
+    single = a.precision == "single"
+    psi = torch.empty((N, D), dtype=torch.complex64 if single else torch.complex128, device=dev)
     psi_real = torch.view_as_real(psi).view(N, 2 * D)
     K = torch.empty((r1 - r0, N), dtype=torch.float64, device=dev)
     sg = sharded.ShardedGram(N, D, rank, world)
@@ -198,7 +202,7 @@ def main():
     T = a.test_rows if a.test_rows >= 0 else (N // 4 if world == 1 else 0)
     if T > 0 and world == 1:
         Xt = torch.from_numpy(rng.uniform(lo, hi, size=(T, n))).to(dev)
-        psi_t = torch.empty((T, D), dtype=torch.complex128, device=dev)
+        psi_t = torch.empty((T, D), dtype=psi.dtype, device=dev)
         Kt = torch.empty((T, N), dtype=torch.float64, device=dev)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
@@ -219,6 +223,7 @@ def main():
     flops_rank = 8.0 * D * entries_rank
     achieved = flops_rank / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0
 
+    PEAK = FP32_MFMA_PEAK_TFLOPS if single else FP64_MFMA_PEAK_TFLOPS
     if rank == 0:
         out = {
             "metric": "Gram kernel entries/sec (whole node) at 16 qubits, N=65536; % FP64 MFMA peak",
@@ -229,7 +234,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if single else "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{n}-qubit zz_featuremap r={a.repeats} fidelity kernel, N={N} train x train "
@@ -237,12 +242,13 @@ def main():
                 "rows": N, "qubits": n, "parallelism": f"row-block x{world}",
             },
             "roofline": {
-                "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(N, n, a.repeats, world),
-                "kernel": "qk::gram_dma_kernel<2,4,4,2,true>", "ms_per_launch_set": gram_ms,
+                "bound": "mfma", "achieved": achieved, "peak": PEAK, "unit": "TFLOP/s",
+                "frac": achieved / PEAK, "traffic": None if single else pmc_traffic(N, n, a.repeats, world),
+                "kernel": "qk::gram32_dma_kernel<2,4,4,2>" if single else "qk::gram_dma_kernel<2,4,4,2,true>",
+                "ms_per_launch_set": gram_ms,
                 "algorithmic_flops": flops_rank,
                 "mfma_flops": 0.75 * flops_rank,
-                "mfma_frac": 0.75 * achieved / FP64_MFMA_PEAK_TFLOPS,
+                "mfma_frac": 0.75 * achieved / PEAK,
                 "note": "achieved = 8*D algorithmic real flops per computed entry (rank 0's share) / kernel time, "
                         "per-GPU peak. The kernel uses the 3-multiplication (Karatsuba) complex product, so the "
                         "matrix cores execute 6*D flops per entry: mfma_frac is the fraction of MFMA issue slots "
@@ -253,7 +259,7 @@ def main():
         }
         if test_block:
             out["test_block"] = test_block
-        if probe:
+        if probe and not single:
             out["roofline"]["mfma_probe_tflops"] = probe["tflops"]
             out["roofline"]["mfma_frac_of_probe"] = 0.75 * achieved / probe["tflops"]
             out["roofline"]["note"] += ("; mfma_probe_tflops = a register-only MFMA loop timed on this box just before "

@@ -130,6 +130,24 @@ int qk_gram_dev(const void* psi_x, int64_t N, const void* psi_y, int64_t M, int6
                 double* K_dev, int64_t ldk, void* stream);
 
 /*
+ * FP32 mode (optional precision of BASELINE.json's north_star; no counterpart in the reference,
+ * whose FidelityStatevectorKernel is always complex128 -- SURVEY.md 8a A4).  The circuit is
+ * evolved in FP64 and rounded once when Psi is stored as complex64 [N][2^n] (re, im float32);
+ * the Gram stage runs on FP32 MFMA with two-level accumulation and still delivers float64 K.
+ * Tolerance: |K - K_fp64| <= 1e-5.  psi_ws_dev: complex128 workspace N x 2^n, needed only when
+ * qk_circuit_num_passes(c) > 1 (NULL otherwise).  Jobs are those of qk_gram_jobs_dev with A, B
+ * pointing at complex64 rows.
+ */
+int qk_simulate_c64_dev(const qk_circuit* c, const double* X_dev, int64_t N, int64_t ldx,
+                        void* psi32_dev, void* psi_ws_dev, void* stream);
+int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream);
+int qk_gram32_dev(const void* psi32_x, int64_t N, const void* psi32_y, int64_t M, int64_t D,
+                  double* K_dev, int64_t ldk, void* stream);
+/* Host-pointer convenience: qk_evaluate with the statevectors and the Gram stage in FP32 mode. */
+int qk_evaluate_f32(const qk_circuit* c, const double* X, int64_t N,
+                    const double* Y, int64_t M, int n_features, double* K_host);
+
+/*
  * Replaces: kernel.evaluate(x_vec, y_vec=None) of FidelityStatevectorKernel
  * (reference qsvm/train.py:92,152,154; qsvm_tester.py:684-686; genetic_v3.py:619).
  * Host pointers; Y == NULL gives the symmetric N x N matrix with unit diagonal.

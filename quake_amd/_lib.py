@@ -62,6 +62,10 @@ SIGNATURES = {
     "qk_simulate": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "qk_gram_jobs_dev": (C.c_int, [C.POINTER(qk_gram_job), C.c_int, _I64, _P]),
     "qk_gram_dev": (C.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
+    "qk_simulate_c64_dev": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
+    "qk_gram32_jobs_dev": (C.c_int, [C.POINTER(qk_gram_job), C.c_int, _I64, _P]),
+    "qk_gram32_dev": (C.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
+    "qk_evaluate_f32": (C.c_int, [_P, _P, _I64, _P, _I64, C.c_int, _P]),
     "qk_evaluate": (C.c_int, [_P, _P, _I64, _P, _I64, C.c_int, _P]),
     "qk_rdm1_dev": (C.c_int, [_P, _I64, C.c_int, _P, _P]),
     "qk_simulate_rdm1_is_fused": (C.c_int, [_P]),

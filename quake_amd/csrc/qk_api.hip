@@ -177,6 +177,36 @@ extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, cons
     return QK_OK;
 }
 
+extern "C" int qk_evaluate_f32(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,
+                               int n_features, double* K_host) {
+    if (!c || !K_host) return fail(QK_ERR_INVALID, "qk_evaluate_f32: null pointer");
+    if (n_features != c->n_params)
+        return fail(QK_ERR_INVALID, "x_vec and class feature map have incompatible dimensions");
+    if (N < 0 || (Y && M < 0)) return fail(QK_ERR_INVALID, "qk_evaluate_f32: negative row count");
+    if (c->n_params > 0 && ((N && !X))) return fail(QK_ERR_INVALID, "qk_evaluate_f32: X is null");
+    const bool sym = (Y == nullptr);
+    if (sym) M = N;
+    if (N == 0 || M == 0) return QK_OK;
+    int rc = check_device();
+    if (rc) return rc;
+    const int F = c->n_params;
+    const int64_t D = (int64_t)1 << c->n_qubits;
+    DevBuf dX, dY, dPx, dPy, dWs, dK;
+    if (c->passes.size() > 1) QK_HIP(dWs.alloc((size_t)std::max(N, M) * D * 16));
+    if ((rc = upload_X(X, N, F, dX))) return rc;
+    QK_HIP(dPx.alloc((size_t)N * D * 8));
+    if ((rc = qk_simulate_c64_dev(c, (const double*)dX.p, N, F, dPx.p, dWs.p, nullptr))) return rc;
+    if (!sym) {
+        if ((rc = upload_X(Y, M, F, dY))) return rc;
+        QK_HIP(dPy.alloc((size_t)M * D * 8));
+        if ((rc = qk_simulate_c64_dev(c, (const double*)dY.p, M, F, dPy.p, dWs.p, nullptr))) return rc;
+    }
+    QK_HIP(dK.alloc((size_t)N * M * sizeof(double)));
+    if ((rc = qk_gram32_dev(dPx.p, N, sym ? nullptr : dPy.p, M, D, (double*)dK.p, M, nullptr))) return rc;
+    QK_HIP(hipMemcpy(K_host, dK.p, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));
+    return QK_OK;
+}
+
 extern "C" int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t N, int n_features, double gamma,
                                    double* K_host) {
     if (!c || !K_host) return fail(QK_ERR_INVALID, "qk_projected_kernel: null pointer");

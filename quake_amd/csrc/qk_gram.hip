@@ -518,6 +518,217 @@ gram_dma_kernel(GramArgs args) {
     gram_epilogue<TM, TN, K3M>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
 }
 
+// ---- FP32 variant (optional precision of BASELINE.json north_star; tolerance 1e-5) -------------
+// Psi rows are interleaved complex64.  Same LDS-DMA geometry with 16-byte units: one unit holds TWO
+// amplitudes, a k-tile is 32 amplitudes, and one b128 fragment read feeds two k-steps of
+// v_mfma_f32_16x16x4_f32 (which amplitude sits in which MFMA k-slot is free as long as A and B
+// agree: lane group g of double-step kk takes the pair 4 kk + g).  3-multiplication product as
+// above.  FP32 accumulation over 2^16 amplitudes would drift past 1e-5, so the three running
+// accumulators only ever hold 1024 amplitudes: every 32 k-tiles they are folded into a second
+// level (Re, Im) and cleared -- 64 second-level additions instead of 16384 first-level ones.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// f32 16x16x4 result layout: col = lane & 15, row = 4 * (lane >> 4) + reg.
+template <int TM, int TN>
+__device__ __forceinline__ void gram32_epilogue(v4f (&re)[TM][TN], v4f (&im)[TM][TN], const GramJobDev& J, int64_t wrow0,
+                                                int64_t wcol0, int lane, bool sym) {
+    double* __restrict__ Kp = J.K;
+    double* __restrict__ KTp = J.KT;
+    const int64_t ldk = J.ldk, ldkt = J.ldkt, ma = J.ma, nb = J.nb;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = wrow0 + m * 16 + 4 * (lane >> 4) + r;
+                const int64_t j = wcol0 + n * 16 + (lane & 15);
+                if (i >= ma || j >= nb) continue;
+                const double x = (double)re[m][n][r], y = (double)im[m][n][r];
+                double v = fma(x, x, y * y);
+                if (sym) {
+                    if (i > j) continue;
+                    if (i == j) v = 1.0;
+                }
+                Kp[i * ldk + j] = v;
+                if (sym && i != j) Kp[j * ldk + i] = v;
+                if (KTp) KTp[j * ldkt + i] = v;
+            }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4)
+gram32_dma_kernel(GramArgs args) {
+    using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, true>;   // BK = 16 units = 32 amplitudes
+    constexpr int KS = 4;
+    constexpr int FLUSH = 32;  // k-tiles per first-level accumulation run (1024 amplitudes)
+    extern __shared__ v4f smem32[];
+    GramJobDev J;
+    int ti, tj;
+    if (!gram_locate(args, C::BM, C::BN, J, ti, tj)) return;
+    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int64_t U = args.D / 2;   // 16-byte units per row
+    const int64_t row0 = (int64_t)ti * C::BM, col0 = (int64_t)tj * C::BN;
+    const int64_t ma = J.ma, nb = J.nb;
+    const v4f* __restrict__ Ag = (const v4f*)J.A;
+    const v4f* __restrict__ Bg = (const v4f*)J.B;
+
+    const v4f* gA[C::NA];
+    const v4f* gB[C::NB];
+#pragma unroll
+    for (int j = 0; j < C::NA; ++j) {
+        const int row = 4 * (wave + C::WAVES * j) + (lane >> 4);
+        gA[j] = Ag + min(row0 + row, ma - 1) * U + ((lane & 15) ^ (row & 15));
+    }
+#pragma unroll
+    for (int j = 0; j < C::NB; ++j) {
+        const int row = 4 * (wave + C::WAVES * j) + (lane >> 4);
+        gB[j] = Bg + min(col0 + row, nb - 1) * U + ((lane & 15) ^ (row & 15));
+    }
+    auto issue_dma = [&](int buf, int64_t off, int part) {
+        v4f* base = smem32 + buf * C::BUF;
+#pragma unroll
+        for (int e = 0; e < C::NA + C::NB; ++e) {
+            if (part >= 0 && (e % 3) != part) continue;
+            if (e < C::NA) {
+                const int j = e < C::NA ? e : 0;
+                __builtin_amdgcn_global_load_lds((gptr_t)(gA[j] + off), (lptr_t)(base + (wave + C::WAVES * j) * 64), 16, 0, 0);
+            } else {
+                const int j = e >= C::NA ? e - C::NA : 0;
+                __builtin_amdgcn_global_load_lds((gptr_t)(gB[j] + off),
+                                                 (lptr_t)(base + C::BM * 16 + (wave + C::WAVES * j) * 64), 16, 0, 0);
+            }
+        }
+    };
+
+    v4f acc[3][TM][TN], hre[TM][TN], him[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            acc[0][m][n] = acc[1][m][n] = acc[2][m][n] = (v4f){0, 0, 0, 0};
+            hre[m][n] = him[m][n] = (v4f){0, 0, 0, 0};
+        }
+    auto flush = [&]() {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                hre[m][n] += acc[0][m][n] + acc[1][m][n];
+                him[m][n] += acc[2][m][n] + (acc[0][m][n] - acc[1][m][n]);
+                acc[0][m][n] = acc[1][m][n] = acc[2][m][n] = (v4f){0, 0, 0, 0};
+            }
+    };
+
+    const int64_t ktiles = U / C::BK;
+    issue_dma(0, 0, -1);
+    __syncthreads();
+
+    const int frag_k = lane >> 4, frag_r = lane & 15;
+    const int a_row = (wm * (TM * 16) + frag_r) * 16;
+    const int b_row = C::BM * 16 + (wn * (TN * 16) + frag_r) * 16;
+    int xs[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) xs[kk] = (4 * kk + frag_k) ^ frag_r;
+
+    v4f a[TM], b[TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[m] = smem32[a_row + m * 256 + xs[0]];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) b[n] = smem32[b_row + n * 256 + xs[0]];
+    for (int64_t kt = 0; kt < ktiles; ++kt) {
+        const int cur = (int)(kt & 1);
+        const int64_t noff = min(kt + 1, ktiles - 1) * C::BK;
+        const v4f* S = smem32 + cur * C::BUF;
+        const v4f* Sn = smem32 + (cur ^ 1) * C::BUF;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            float sa[2][TM], db[2][TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) { sa[0][m] = a[m].x + a[m].y; sa[1][m] = a[m].z + a[m].w; }
+#pragma unroll
+            for (int n = 0; n < TN; ++n) { db[0][n] = b[n].y - b[n].x; db[1][n] = b[n].w - b[n].z; }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk < 3) issue_dma(cur ^ 1, noff, kk);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[2][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][m], db[0][n], acc[2][m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b[n].z, acc[0][m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b[n].w, acc[1][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // fragments of the next step: a, b are dead from here (the last products use sa / db)
+            if (kk < KS - 1) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m) a[m] = S[a_row + m * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) b[n] = S[b_row + n * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < TM; ++m) a[m] = Sn[a_row + m * 256 + xs[0]];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) b[n] = Sn[b_row + n * 256 + xs[0]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[2][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][m], db[1][n], acc[2][m][n], 0, 0, 0);
+        }
+        if ((kt & (FLUSH - 1)) == FLUSH - 1) flush();
+    }
+    flush();
+    gram32_epilogue<TM, TN>(hre, him, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
+}
+
+// D < 32 (under 5 qubits): one thread per entry, FP32 products accumulated in order.
+__global__ void __launch_bounds__(256) gram32_small_kernel(GramArgs args) {
+    const GramJobDev& J = args.job[0];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= J.ma * J.nb) return;
+    const int64_t i = e / J.nb, j = e % J.nb;
+    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+    // symmetric block: both (i, j) and (j, i) are computed from the ordered pair, so they agree bitwise
+    const int64_t p = sym && i > j ? j : i, q = sym && i > j ? i : j;
+    const float2* a = (const float2*)J.A + p * args.D;
+    const float2* b = (const float2*)J.B + q * args.D;
+    float re = 0.f, im = 0.f;
+    for (int64_t k = 0; k < args.D; ++k) {
+        re = fmaf(a[k].x, b[k].x, fmaf(a[k].y, b[k].y, re));
+        im = fmaf(a[k].x, b[k].y, fmaf(-a[k].y, b[k].x, im));
+    }
+    double v = fma((double)re, (double)re, (double)im * (double)im);
+    if (sym && i == j) v = 1.0;
+    J.K[i * J.ldk + j] = v;
+    if (J.KT) J.KT[j * J.ldkt + i] = v;
+}
+
 // ---- variants ------------------------------------------------------------------
 struct Variant {
     const char* name;
@@ -594,29 +805,26 @@ extern "C" int qk_gram_set_variant(const char* name) {
 }
 
 
-extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
-    using namespace qk;
-    if (!jobs || n_jobs < 1 || n_jobs > QK_GRAM_MAX_JOBS)
-        return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: need 1..16 jobs");
-    if (D < 1 || (D & (D - 1)) != 0) return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: D must be a power of two");
-    int vi = pick_variant();
-    if (D < kVariants[vi].min_d) vi = 0;  // LDS-DMA tiles need 16 amplitudes per k-tile; tiny circuits use variant 0
-    const Variant& V = kVariants[vi];
-    GramArgs args;
+namespace qk {
+// validate the jobs and lay them out on the tile schedule of (bm x bn) block tiles
+static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int bm, int bn, const char* who, GramArgs& args,
+                           int64_t& blocks) {
+    if (!jobs || n_jobs < 1 || n_jobs > QK_GRAM_MAX_JOBS) return fail(QK_ERR_INVALID, std::string(who) + ": need 1..16 jobs");
+    if (D < 1 || (D & (D - 1)) != 0) return fail(QK_ERR_INVALID, std::string(who) + ": D must be a power of two");
     std::memset(&args, 0, sizeof(args));
     args.D = D;
-    int64_t blocks = 0;
+    blocks = 0;
     int nj = 0;
     for (int k = 0; k < n_jobs; ++k) {
         const qk_gram_job& j = jobs[k];
-        if (j.ma < 0 || j.nb < 0) return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: negative block size");
+        if (j.ma < 0 || j.nb < 0) return fail(QK_ERR_INVALID, std::string(who) + ": negative block size");
         if (j.ma == 0 || j.nb == 0) continue;
-        if (!j.A || !j.B || !j.K) return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: null pointer in job");
+        if (!j.A || !j.B || !j.K) return fail(QK_ERR_INVALID, std::string(who) + ": null pointer in job");
         if (j.ldk < j.nb || (j.KT && j.ldkt < j.ma))
-            return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: leading dimension smaller than the block");
+            return fail(QK_ERR_INVALID, std::string(who) + ": leading dimension smaller than the block");
         const bool sym = (j.flags & QK_GRAM_SYMMETRIC) != 0;
         if (sym && (j.ma != j.nb || j.A != j.B))
-            return fail(QK_ERR_INVALID, "qk_gram_jobs_dev: a symmetric job needs A == B and ma == nb");
+            return fail(QK_ERR_INVALID, std::string(who) + ": a symmetric job needs A == B and ma == nb");
         GramJobDev& d = args.job[nj++];
         d.A = (const double2*)j.A;
         d.B = (const double2*)j.B;
@@ -624,14 +832,14 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
         d.KT = j.KT;
         d.ma = j.ma; d.nb = j.nb; d.ldk = j.ldk; d.ldkt = j.ldkt;
         d.flags = j.flags;
-        d.tiles_m = (int32_t)((j.ma + V.bm - 1) / V.bm);
-        d.tiles_n = (int32_t)((j.nb + V.bn - 1) / V.bn);
+        d.tiles_m = (int32_t)((j.ma + bm - 1) / bm);
+        d.tiles_n = (int32_t)((j.nb + bn - 1) / bn);
         d.block_begin = blocks;
         const int C8 = (d.tiles_n + 7) / 8, R4 = (d.tiles_m + 3) / 4;
         int64_t macros = 0;
         if (sym) {
             for (int R = 0; R < R4; ++R) {
-                const int cnt = C8 - (R * V.bm) / (2 * V.bn);
+                const int cnt = C8 - (R * bm) / (2 * bn);
                 if (cnt <= 0) break;
                 macros += cnt;
             }
@@ -640,14 +848,61 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
         }
         blocks += ((macros + 7) / 8) * 256;  // whole rounds of 8 macro-tiles keep block_begin % 256 == 0
     }
-    if (nj == 0) return QK_OK;
     args.n_jobs = nj;
-    if (blocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, "qk_gram_jobs_dev: too many tiles; split the call");
+    if (blocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, std::string(who) + ": too many tiles; split the call");
+    return QK_OK;
+}
+}  // namespace qk
+
+extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
+    using namespace qk;
+    int vi = pick_variant();
+    if (D < kVariants[vi].min_d) vi = 0;  // LDS-DMA tiles need 16 amplitudes per k-tile; tiny circuits use variant 0
+    const Variant& V = kVariants[vi];
+    GramArgs args;
+    int64_t blocks = 0;
+    const int rc = build_gram_args(jobs, n_jobs, D, V.bm, V.bn, "qk_gram_jobs_dev", args, blocks);
+    if (rc) return rc;
+    if (args.n_jobs == 0) return QK_OK;
     if (!g_attr_set[vi]) {
         QK_HIP(hipFuncSetAttribute(V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds));
         g_attr_set[vi] = true;
     }
     V.launch(args, (unsigned)blocks, (hipStream_t)stream);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
+    using namespace qk;
+    using C = GramDmaCfg<2, 4, 4, 2, true>;
+    GramArgs args;
+    int64_t blocks = 0;
+    const int rc = build_gram_args(jobs, n_jobs, D, C::BM, C::BN, "qk_gram32_jobs_dev", args, blocks);
+    if (rc) return rc;
+    if (args.n_jobs == 0) return QK_OK;
+    if (D < 32) {   // under 5 qubits: one launch per job, one thread per entry
+        for (int k = 0; k < args.n_jobs; ++k) {
+            GramArgs one;
+            std::memset(&one, 0, sizeof(one));
+            one.D = D;
+            one.n_jobs = 1;
+            one.job[0] = args.job[k];
+            const int64_t entries = one.job[0].ma * one.job[0].nb;
+            if ((entries + 255) / 256 > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, "qk_gram32_jobs_dev: block too large");
+            hipLaunchKernelGGL(gram32_small_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream, one);
+        }
+        QK_HIP(hipGetLastError());
+        return QK_OK;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        QK_HIP(hipFuncSetAttribute((const void*)gram32_dma_kernel<2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gram32_dma_kernel<2, 4, 4, 2>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
+                       (hipStream_t)stream, args);
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
@@ -665,4 +920,19 @@ extern "C" int qk_gram_dev(const void* psi_x, int64_t N, const void* psi_y, int6
     j.ldk = ldk;
     j.flags = psi_y ? 0 : QK_GRAM_SYMMETRIC;
     return qk_gram_jobs_dev(&j, 1, D, stream);
+}
+
+extern "C" int qk_gram32_dev(const void* psi_x, int64_t N, const void* psi_y, int64_t M, int64_t D,
+                             double* K_dev, int64_t ldk, void* stream) {
+    qk_gram_job j;
+    std::memset(&j, 0, sizeof(j));
+    j.A = psi_x;
+    j.B = psi_y ? psi_y : psi_x;
+    j.K = K_dev;
+    j.KT = nullptr;
+    j.ma = N;
+    j.nb = psi_y ? M : N;
+    j.ldk = ldk;
+    j.flags = psi_y ? 0 : QK_GRAM_SYMMETRIC;
+    return qk_gram32_jobs_dev(&j, 1, D, stream);
 }

@@ -24,6 +24,7 @@ struct SimArgs {
     const double* X;
     int64_t ldx;
     double2* psi;   // may be null in fused-RDM mode (the statevectors are never written)
+    float2* psi32;  // FP32 output (qk_simulate_c64_dev): the state is evolved in FP64 and rounded once, at the store
     double* rdm;    // fused mode: N x n x 4 reduced density matrices, computed from LDS (single chunk per sample)
     int64_t D;  // amplitudes per sample
     const DevStage* stages;
@@ -458,9 +459,16 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             for (int t = tid + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
         __syncthreads();
         if constexpr (RDM) rdm1_from_lds(state, L, s_red, a.rdm + sample * (L * 4), tid, T);
-        if (!RDM || a.psi)
+        if (a.psi32) {      // only on the last pass: intermediate passes stay FP64
+            float2* g32 = a.psi32 + sample * a.D;
+            for (uint32_t l = tid; l < nloc; l += T) {
+                const double2 v = state[l];
+                g32[chunk_phys | deposit(l, a)] = make_float2((float)v.x, (float)v.y);
+            }
+        } else if (!RDM || a.psi) {
             for (uint32_t l = tid; l < nloc; l += T)
                 if (!(l & a.zero_out)) gpsi[chunk_phys | deposit(l, a)] = state[l];
+        }
         // LDS is reused by the next item.  A bare barrier: every wave's LDS reads have returned
         // before it issued its stores, and the stores themselves need not have landed.
         __builtin_amdgcn_s_barrier();
@@ -503,8 +511,10 @@ void free_circuit_device(qk_circuit& c) {
 
 namespace qk {
 // psi and / or rdm: rdm != null asks for the fused mode (one pass, one chunk per sample)
+// psi32 != null: the last pass writes complex64 there; with several passes psi_dev (complex128) is
+// the workspace the earlier passes go through.
 static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx, void* psi_dev, double* rdm_dev,
-                         void* stream) {
+                         void* stream, void* psi32_dev = nullptr) {
     qk_circuit& c = *const_cast<qk_circuit*>(cc);
     if (c.n_params > 0 && (!X_dev || ldx < c.n_params))
         return fail(QK_ERR_INVALID, "qk_simulate_dev: X is null or its row stride is smaller than the parameter count");
@@ -519,8 +529,10 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    for (const Pass& ps : c.passes) {
+    for (size_t pi = 0; pi < c.passes.size(); ++pi) {
+        const Pass& ps = c.passes[pi];
         SimArgs a{};
+        a.psi32 = (psi32_dev && pi + 1 == c.passes.size()) ? (float2*)psi32_dev : nullptr;
         a.X = X_dev;
         a.ldx = ldx;
         a.psi = (double2*)psi_dev;
@@ -592,6 +604,17 @@ extern "C" int qk_simulate_dev(const qk_circuit* cc, const double* X_dev, int64_
     if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate_dev: negative N");
     if (N == 0) return QK_OK;
     return simulate_impl(cc, X_dev, N, ldx, psi_dev, nullptr, stream);
+}
+
+extern "C" int qk_simulate_c64_dev(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx, void* psi32_dev,
+                                   void* psi_ws_dev, void* stream) {
+    using namespace qk;
+    if (!cc || !psi32_dev) return fail(QK_ERR_INVALID, "qk_simulate_c64_dev: null circuit or output");
+    if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate_c64_dev: negative N");
+    if (N == 0) return QK_OK;
+    if (cc->passes.size() > 1 && !psi_ws_dev)
+        return fail(QK_ERR_INVALID, "qk_simulate_c64_dev: a multi-pass circuit needs the complex128 workspace");
+    return simulate_impl(cc, X_dev, N, ldx, psi_ws_dev, nullptr, stream, psi32_dev);
 }
 
 extern "C" int qk_simulate_rdm1_dev(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx, double* rdm_dev,

@@ -40,8 +40,9 @@ class DeviceCircuit:
         self.n_params = self.compiled.n_params
         self.dim = 1 << self.n_qubits
 
-    def simulate(self, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """X float64 [N, n_params] (row stride free) -> Psi complex128 [N, 2^n]."""
+    def simulate(self, X: torch.Tensor, out: Optional[torch.Tensor] = None, dtype=torch.complex128) -> torch.Tensor:
+        """X float64 [N, n_params] (row stride free) -> Psi [N, 2^n], complex128 or (FP32 mode:
+        evolved in FP64, rounded at the store) complex64 -- the dtype of ``out`` if given."""
         _require_gpu(X, out)
         if X.dtype != torch.float64 or X.dim() != 2 or X.stride(1) != 1:
             raise ValueError("X must be a float64 [N, F] tensor with unit column stride")
@@ -51,11 +52,19 @@ class DeviceCircuit:
                 f"x_vec has {X.shape[1]} dimensions, but feature map has {self.n_params}.")
         N = X.shape[0]
         if out is None:
-            out = torch.empty((N, self.dim), dtype=torch.complex128, device=X.device)
-        elif out.dtype != torch.complex128 or tuple(out.shape) != (N, self.dim) or not out.is_contiguous():
-            raise ValueError("out must be a contiguous complex128 [N, 2^n] tensor")
+            out = torch.empty((N, self.dim), dtype=dtype, device=X.device)
+        elif out.dtype not in (torch.complex128, torch.complex64) or tuple(out.shape) != (N, self.dim) \
+                or not out.is_contiguous():
+            raise ValueError("out must be a contiguous complex128 / complex64 [N, 2^n] tensor")
         ldx = X.stride(0) if N > 1 else max(self.n_params, 1)
-        _lib.check(_lib.load().qk_simulate_dev(self.handle.handle, _dp(X), N, ldx, _dp(out), _stream_ptr()))
+        lib = _lib.load()
+        if out.dtype == torch.complex128:
+            _lib.check(lib.qk_simulate_dev(self.handle.handle, _dp(X), N, ldx, _dp(out), _stream_ptr()))
+        else:
+            ws = None
+            if self.handle.num_passes > 1:     # earlier passes go through a complex128 workspace
+                ws = torch.empty((N, self.dim), dtype=torch.complex128, device=X.device)
+            _lib.check(lib.qk_simulate_c64_dev(self.handle.handle, _dp(X), N, ldx, _dp(out), _dp(ws), _stream_ptr()))
         return out
 
 
@@ -79,14 +88,18 @@ def simulate_rdm1(circuit: "DeviceCircuit", X: torch.Tensor) -> torch.Tensor:
 
 def gram_jobs(jobs: Sequence[dict], D: int) -> None:
     """Run several block jobs in one launch.  Each job: dict(A=, B=, K=, KT=None, symmetric=False);
-    A, B complex128 [rows, D] contiguous; K (and KT) float64 2-D views with unit column stride."""
+    A, B complex128 (or, for the FP32 Gram stage, complex64) [rows, D] contiguous; K (and KT) float64
+    2-D views with unit column stride."""
     arr = (_lib.qk_gram_job * len(jobs))()
+    dtype = jobs[0]["A"].dtype if jobs else torch.complex128
+    if dtype not in (torch.complex128, torch.complex64):
+        raise ValueError("statevectors must be complex128 or complex64")
     for k, j in enumerate(jobs):
         A, B, K, KT = j["A"], j["B"], j["K"], j.get("KT")
         _require_gpu(A, B, K, KT)
         for t in (A, B):
-            if t.dtype != torch.complex128 or t.dim() != 2 or t.shape[1] != D or not t.is_contiguous():
-                raise ValueError("A and B must be contiguous complex128 [rows, D]")
+            if t.dtype != dtype or t.dim() != 2 or t.shape[1] != D or not t.is_contiguous():
+                raise ValueError("A and B must be contiguous [rows, D] of one complex dtype")
         if K.dtype != torch.float64 or K.stride(1) != 1 or tuple(K.shape) != (A.shape[0], B.shape[0]):
             raise ValueError("K must be float64 [rows(A), rows(B)] with unit column stride")
         if KT is not None and (KT.dtype != torch.float64 or KT.stride(1) != 1
@@ -99,7 +112,8 @@ def gram_jobs(jobs: Sequence[dict], D: int) -> None:
         arr[k].ldk = K.stride(0) if K.shape[0] > 1 else max(K.shape[1], 1)
         arr[k].ldkt = (KT.stride(0) if KT.shape[0] > 1 else max(KT.shape[1], 1)) if KT is not None else 0
         arr[k].flags = _lib.QK_GRAM_SYMMETRIC if j.get("symmetric") else 0
-    _lib.check(_lib.load().qk_gram_jobs_dev(arr, len(jobs), D, _stream_ptr()))
+    fn = _lib.load().qk_gram_jobs_dev if dtype == torch.complex128 else _lib.load().qk_gram32_jobs_dev
+    _lib.check(fn(arr, len(jobs), D, _stream_ptr()))
 
 
 def gram(psi_x: torch.Tensor, psi_y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

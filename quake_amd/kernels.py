@@ -65,7 +65,12 @@ class HipFidelityKernel:
     def __init__(self, feature_map: QuantumCircuit, *, enforce_psd: bool = False,
                  training_parameters: Optional[Sequence[Parameter]] = None,
                  parameter_values: Optional[Sequence[float]] = None,
-                 shots=None, cache_size=None, auto_clear_cache: bool = True):
+                 shots=None, cache_size=None, auto_clear_cache: bool = True, precision: str = "double"):
+        if precision not in ("double", "single"):
+            raise ValueError("precision must be 'double' or 'single'")
+        # 'single': statevectors stored as complex64 and the Gram stage on FP32 MFMA (|dK| <= 1e-5); a
+        # build option with no counterpart in the reference, whose kernel is always complex128
+        self._precision = precision
         if shots is not None and int(shots) < 1:
             raise ValueError("shots must be a positive integer")
         self._shots = int(shots) if shots is not None else None
@@ -157,7 +162,7 @@ class HipFidelityKernel:
         circ = self._circuit()
         n, m = x.shape[0], (x.shape[0] if y is None else y.shape[0])
         K = np.empty((n, m), dtype=np.float64)
-        _lib.check(lib.qk_evaluate(
+        _lib.check((lib.qk_evaluate if self._precision == "double" else lib.qk_evaluate_f32)(
             circ.handle, _lib.ptr(x), n,
             _lib.ptr(y) if y is not None else None, m, x.shape[1], _lib.ptr(K)))
         if y is None and self._enforce_psd:
