@@ -148,6 +148,85 @@ extern "C" int qk_simulate(const qk_circuit* c, const double* X, int64_t N, int6
     return QK_OK;
 }
 
+namespace qk {
+namespace {
+// The Gram stage of the host entry points, with the copy of K back to the host hidden behind it.
+// K is produced in row bands (each band = one multi-job launch: its diagonal block as a symmetric job,
+// the block to its right as a cross job whose transposed copy fills the mirror entries of the later
+// bands).  A band's rows are final once its launch has finished -- everything left of its diagonal
+// block was written by earlier bands -- so the host copies band b while the GPU computes band b + 1.
+// f32: the statevectors are complex64 (qk_gram32_jobs_dev).
+int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t D, bool f32, double* K_host) {
+    const bool sym = (dPy == nullptr);
+    const size_t esz = f32 ? 8 : 16;
+    auto launch = f32 ? qk_gram32_jobs_dev : qk_gram_jobs_dev;
+    DevBuf dK;
+    QK_HIP(dK.alloc((size_t)N * M * sizeof(double)));
+    double* K = (double*)dK.p;
+    int64_t nbands = std::min<int64_t>(16, N / 1024);   // bands of >= 1024 rows; small problems: one launch, one copy
+    if (nbands < 2) nbands = 1;
+    const int64_t band = ((N + nbands - 1) / nbands + 127) / 128 * 128;
+    hipStream_t compute = nullptr, copy = nullptr;
+    std::vector<hipEvent_t> done;
+    int rc = QK_OK;
+    auto cleanup = [&]() {
+        for (hipEvent_t e : done) (void)hipEventDestroy(e);
+        if (compute) (void)hipStreamDestroy(compute);
+        if (copy) (void)hipStreamDestroy(copy);
+    };
+    if (hipStreamCreateWithFlags(&compute, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) {
+        cleanup();
+        return fail(QK_ERR_HIP, "gram_to_host: cannot create streams");
+    }
+    // the simulations ran on the null stream: order the compute stream behind them
+    if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return fail(QK_ERR_HIP, "gram_to_host: device synchronisation failed"); }
+    for (int64_t r0 = 0; r0 < N && rc == QK_OK; r0 += band) {
+        const int64_t r1 = std::min(N, r0 + band);
+        qk_gram_job jobs[2];
+        std::memset(jobs, 0, sizeof(jobs));
+        int nj = 0;
+        const char* A = (const char*)dPx + (size_t)r0 * D * esz;
+        if (sym) {
+            jobs[nj].A = A; jobs[nj].B = A; jobs[nj].K = K + r0 * M + r0;
+            jobs[nj].ma = jobs[nj].nb = r1 - r0; jobs[nj].ldk = M; jobs[nj].flags = QK_GRAM_SYMMETRIC;
+            ++nj;
+            if (r1 < N) {
+                jobs[nj].A = A; jobs[nj].B = (const char*)dPx + (size_t)r1 * D * esz;
+                jobs[nj].K = K + r0 * M + r1; jobs[nj].KT = K + r1 * M + r0;
+                jobs[nj].ma = r1 - r0; jobs[nj].nb = N - r1; jobs[nj].ldk = M; jobs[nj].ldkt = M;
+                ++nj;
+            }
+        } else {
+            jobs[nj].A = A; jobs[nj].B = dPy; jobs[nj].K = K + r0 * M;
+            jobs[nj].ma = r1 - r0; jobs[nj].nb = M; jobs[nj].ldk = M;
+            ++nj;
+        }
+        rc = launch(jobs, nj, D, compute);
+        hipEvent_t e;
+        if (rc == QK_OK && (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess ||
+                            hipEventRecord(e, compute) != hipSuccess))
+            rc = fail(QK_ERR_HIP, "gram_to_host: cannot record event");
+        else if (rc == QK_OK)
+            done.push_back(e);
+    }
+    // every launch is queued; now drain band by band while the later bands compute
+    size_t b = 0;
+    for (int64_t r0 = 0; r0 < N && rc == QK_OK; r0 += band, ++b) {
+        const int64_t r1 = std::min(N, r0 + band);
+        if (hipStreamWaitEvent(copy, done[b], 0) != hipSuccess ||
+            hipMemcpyAsync(K_host + r0 * M, K + r0 * M, (size_t)(r1 - r0) * M * sizeof(double), hipMemcpyDeviceToHost, copy) !=
+                hipSuccess ||
+            hipStreamSynchronize(copy) != hipSuccess)
+            rc = fail(QK_ERR_HIP, "gram_to_host: copy of K failed");
+    }
+    if (hipDeviceSynchronize() != hipSuccess && rc == QK_OK) rc = fail(QK_ERR_HIP, "gram_to_host: device synchronisation failed");
+    cleanup();
+    return rc;
+}
+}  // namespace
+}  // namespace qk
+
 extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,
                            int n_features, double* K_host) {
     if (!c || !K_host) return fail(QK_ERR_INVALID, "qk_evaluate: null pointer");
@@ -162,7 +241,7 @@ extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, cons
     if (rc) return rc;
     const int F = c->n_params;
     const int64_t D = (int64_t)1 << c->n_qubits;
-    DevBuf dX, dY, dPx, dPy, dK;
+    DevBuf dX, dY, dPx, dPy;
     if ((rc = upload_X(X, N, F, dX))) return rc;
     QK_HIP(dPx.alloc((size_t)N * D * 16));
     if ((rc = qk_simulate_dev(c, (const double*)dX.p, N, F, dPx.p, nullptr))) return rc;
@@ -171,10 +250,7 @@ extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, cons
         QK_HIP(dPy.alloc((size_t)M * D * 16));
         if ((rc = qk_simulate_dev(c, (const double*)dY.p, M, F, dPy.p, nullptr))) return rc;
     }
-    QK_HIP(dK.alloc((size_t)N * M * sizeof(double)));
-    if ((rc = qk_gram_dev(dPx.p, N, sym ? nullptr : dPy.p, M, D, (double*)dK.p, M, nullptr))) return rc;
-    QK_HIP(hipMemcpy(K_host, dK.p, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));
-    return QK_OK;
+    return gram_to_host(dPx.p, N, sym ? nullptr : dPy.p, M, D, false, K_host);
 }
 
 extern "C" int qk_evaluate_f32(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,
@@ -191,7 +267,7 @@ extern "C" int qk_evaluate_f32(const qk_circuit* c, const double* X, int64_t N, 
     if (rc) return rc;
     const int F = c->n_params;
     const int64_t D = (int64_t)1 << c->n_qubits;
-    DevBuf dX, dY, dPx, dPy, dWs, dK;
+    DevBuf dX, dY, dPx, dPy, dWs;
     if (c->passes.size() > 1) QK_HIP(dWs.alloc((size_t)std::max(N, M) * D * 16));
     if ((rc = upload_X(X, N, F, dX))) return rc;
     QK_HIP(dPx.alloc((size_t)N * D * 8));
@@ -201,10 +277,7 @@ extern "C" int qk_evaluate_f32(const qk_circuit* c, const double* X, int64_t N, 
         QK_HIP(dPy.alloc((size_t)M * D * 8));
         if ((rc = qk_simulate_c64_dev(c, (const double*)dY.p, M, F, dPy.p, dWs.p, nullptr))) return rc;
     }
-    QK_HIP(dK.alloc((size_t)N * M * sizeof(double)));
-    if ((rc = qk_gram32_dev(dPx.p, N, sym ? nullptr : dPy.p, M, D, (double*)dK.p, M, nullptr))) return rc;
-    QK_HIP(hipMemcpy(K_host, dK.p, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));
-    return QK_OK;
+    return gram_to_host(dPx.p, N, sym ? nullptr : dPy.p, M, D, true, K_host);
 }
 
 extern "C" int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t N, int n_features, double gamma,

@@ -252,3 +252,18 @@ def test_gram_raw_layout_asymmetric():
         np.fill_diagonal(refs, 1.0)
         assert np.abs(S[1:N + 1, 2:N + 2] - refs).max() < 1e-13 * refs.max()
         assert (S[0] == -1).all() and (S[:, :2] == -1).all() and (S[N + 1:] == -1).all() and (S[:, N + 2:] == -1).all()
+
+
+@pytest.mark.parametrize("precision,tol", [("double", TOL_K), ("single", 1e-5)])
+def test_host_path_row_bands(precision, tol):
+    """Above 2048 rows the host entry point computes K in row bands and copies each band back while
+    the next one is computed: symmetric (mirror entries come from earlier bands) and cross blocks."""
+    n, N, M = 5, 3300, 700
+    circ, oops, _ = map_pairs(n, 1)["zz"]
+    X, Y = synth_X(N, n, "scaled", 77), synth_X(M, n, "scaled", 78)
+    k = HipFidelityKernel(circ, precision=precision)
+    K = k.evaluate(X)
+    ref = O.evaluate(oops, n, X)
+    assert np.array_equal(K, K.T) and (np.diag(K) == 1.0).all()
+    assert np.abs(K - ref).max() < tol
+    assert np.abs(k.evaluate(X, Y) - O.evaluate(oops, n, X, Y)).max() < tol
