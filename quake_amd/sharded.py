@@ -190,3 +190,22 @@ def sharded_projected_kernel(rdm_local, gamma: float, rank: int = 0, world: int 
     if r0 + nloc < world * nloc:
         pqk_fn(rdm_local, table[r0 + nloc:], gamma, out[:, r0 + nloc:])
     return out
+
+
+def sharded_cross_gram(psi_test_local, psi_train_full, gather_work=None, gram_jobs=None, out=None):
+    """Test x train block of one rank (config 5's 16384 test rows): the test rows are sharded like the
+    train rows, the replicated train statevectors (the all-gather of :class:`ShardedGram`, reused) are
+    the other operand, so the rank's ``[T/G, N]`` block needs no further exchange.
+    ``gather_work`` is the pending all-gather of ``psi_train_full``, if it has not been waited on."""
+    import torch
+
+    if gram_jobs is None:
+        from .device import gram_jobs
+    if gather_work is not None:
+        gather_work.wait()
+    T, D = psi_test_local.shape
+    N = psi_train_full.shape[0]
+    if out is None:
+        out = torch.empty((T, N), dtype=torch.float64, device=psi_test_local.device)
+    gram_jobs([dict(A=psi_test_local, B=psi_train_full, K=out, symmetric=False)], D)
+    return out

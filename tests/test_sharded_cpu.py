@@ -129,3 +129,28 @@ def _pqk_worker(rank, world, port, N, n):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_projected_kernel_over_gloo(world):
     mp.spawn(_pqk_worker, args=(world, _free_port(), 6 * world, 3), nprocs=world, join=True)
+
+
+def _cross_worker(rank, world, port, N, T, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(21)
+        X, Xt = rng.uniform(-1.5, 1.5, size=(N, n)), rng.uniform(-1.5, 1.5, size=(T, n))
+        ops = O.zz_featuremap(n, 1)
+        r0, r1 = sharded.row_range(rank, world, N)
+        t0, t1 = sharded.row_range(rank, world, T)
+        psi_full = torch.zeros((N, 1 << n), dtype=torch.complex128)
+        local = torch.from_numpy(O.statevectors(ops, n, X[r0:r1]))
+        psi_full[r0:r1] = local
+        work = dist.all_gather_into_tensor(psi_full, local, async_op=True)
+        psi_test = torch.from_numpy(O.statevectors(ops, n, Xt[t0:t1]))
+        Kt = sharded.sharded_cross_gram(psi_test, psi_full, gather_work=work, gram_jobs=_cpu_gram_jobs)
+        assert np.abs(Kt.numpy() - O.evaluate(ops, n, Xt, X)[t0:t1]).max() < 1e-13
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_test_block_over_gloo():
+    mp.spawn(_cross_worker, args=(2, _free_port(), 12, 6, 3), nprocs=2, join=True)
