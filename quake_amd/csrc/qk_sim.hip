@@ -102,10 +102,30 @@ __device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, con
     double2 m[NG][4];
     uint32_t lm[NG];
     int form[NG];
+    // Target bits below 4 make consecutive lanes walk LDS with a 2^t-amplitude stride (2^t-way bank
+    // conflicts on the 16-byte accesses).  Remedy: lane l reads register k from the amplitude whose
+    // low target bits are k ^ X(l), X taken from the lane bits that would otherwise only select the
+    // 256-byte row -- 16 consecutive lanes then cover all 16 slots of a row.  Registers k and k ^ m
+    // still hold a pair that differs in target bit m; where X has that bit set the pair is held
+    // in swapped order, which is the same as applying the gate with its rows and columns swapped.
+    int t_low = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t_low += st.gv[g] < 4 ? 1 : 0;
+    uint32_t X = 0;
+    if ((nloc >> NG) >= 16u) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if (g < t_low) X |= (((uint32_t)tid >> (4 - t_low + g)) & 1u) << g;
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[g][k] = mat[4 * st.gm[g] + k];
+        if ((X >> g) & 1u) {
+            double2 t0 = m[g][0], t1 = m[g][1];
+            m[g][0] = m[g][3]; m[g][3] = t0;
+            m[g][1] = m[g][2]; m[g][2] = t1;
+        }
         lm[g] = (1u << st.gv[g]) - 1u;
         const int gate = mats[st.gm[g]].gate;
         form[g] = (gate == QK_H || gate == QK_X || gate == QK_RY) ? 0 : (gate == QK_RX ? 1 : 2);
@@ -118,9 +138,10 @@ __device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, con
         uint32_t idx[1 << NG];
 #pragma unroll
         for (int k = 0; k < (1 << NG); ++k) {
+            const uint32_t kx = (uint32_t)k ^ X;
             uint32_t o = b;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) o |= ((k >> g) & 1u) << st.gv[g];
+            for (int g = 0; g < NG; ++g) o |= ((kx >> g) & 1u) << st.gv[g];
             idx[k] = o;
             v[k] = state[o];
         }
