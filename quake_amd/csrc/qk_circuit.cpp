@@ -196,7 +196,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         ps.first = (pi == 0);
         ps.lgT = ps.L >= 13 ? 9 : (ps.L >= 9 ? 8 : std::max(6, ps.L - 1));
         ps.h = ps.L <= 6 ? ps.L : 6;    // 64 columns = one wavefront; <= kMaxRowBits row bits
-        ps.maxg = ps.L >= 13 ? 3 : 2;   // radix-8 sweeps need the 512-thread / 256-VGPR kernel
+        ps.maxg = ps.L >= 12 ? 3 : 2;   // radix-8 sweeps need the 512-thread / 256-VGPR kernel
         ps.phys = d.S;
         for (int q = 0; q < n; ++q)
             if (std::find(d.S.begin(), d.S.end(), q) == d.S.end()) ps.phys.push_back(q);
