@@ -110,6 +110,18 @@ def mfma_probe(seconds=1.0):
         return None
 
 
+def gram_kernel_name(rows, D):
+    """Which gram_dma_kernel instantiation a block of `rows` rows runs on (the library picks per call)."""
+    import ctypes as C
+    from quake_amd import _lib
+    lib = _lib.load()
+    lib.qk_gram_variant_for.restype = C.c_char_p
+    lib.qk_gram_variant_for.argtypes = [C.c_int64, C.c_int64]
+    name = lib.qk_gram_variant_for(rows, D).decode()
+    return {"dma3m_128x128_w8": "qk::gram_dma_kernel<2,4,4,2,true> (128x128 tiles)",
+            "dma3m_64x64_w4": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles)"}.get(name, name)
+
+
 def pmc_traffic(N, n, repeats, world):
     """HBM bytes per Gram launch from the committed PMC passes (profiles/), when this is the
     workload they were taken on; collected per the guide (separate --pmc passes, FETCH_SIZE x2)."""
@@ -244,7 +256,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK, "unit": "TFLOP/s",
                 "frac": achieved / PEAK, "traffic": None if single else pmc_traffic(N, n, a.repeats, world),
-                "kernel": "qk::gram32_dma_kernel<2,4,4,2>" if single else "qk::gram_dma_kernel<2,4,4,2,true>",
+                "kernel": "qk::gram32_dma_kernel<2,4,4,2>" if single else gram_kernel_name(N // world, D),
                 "ms_per_launch_set": gram_ms,
                 "algorithmic_flops": flops_rank,
                 "mfma_flops": 0.75 * flops_rank,

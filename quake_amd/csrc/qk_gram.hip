@@ -21,6 +21,7 @@
 // and B rows (4x); symmetric jobs list only macro-tiles that reach the diagonal.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -45,6 +46,7 @@ struct GramJobDev {
 struct GramArgs {
     GramJobDev job[QK_GRAM_MAX_JOBS];
     int n_jobs;
+    int lr, lc;  // log2 of the macro-tile shape in block tiles (rows, columns): 4 x 8 for 128 x 128 tiles
     int64_t D;  // amplitudes per row
 };
 
@@ -64,27 +66,28 @@ __device__ __forceinline__ bool gram_locate(const GramArgs& args, int BM, int BN
     const int64_t lb = bid - J.block_begin;
     const int xcd = (int)(lb & 7);
     const int64_t seq = lb >> 3;                       // position in this XCD's stream
-    int64_t mt = (seq >> 5) * 8 + xcd;                 // macro-tile index within the job
-    const int tin = (int)(seq & 31);
+    const int lr = args.lr, lc = args.lc;
+    int64_t mt = (seq >> (lr + lc)) * 8 + xcd;         // macro-tile index within the job
+    const int tin = (int)(seq & ((1 << (lr + lc)) - 1));
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
-    const int C8 = (J.tiles_n + 7) >> 3, R4 = (J.tiles_m + 3) >> 2;
+    const int CG = (J.tiles_n + (1 << lc) - 1) >> lc, RG = (J.tiles_m + (1 << lr) - 1) >> lr;
     int R = 0, Cg;
     if (sym) {
         for (;; ++R) {
-            if (R >= R4) return false;
-            const int cg0 = (R * BM) / (2 * BN);  // first column group that reaches the diagonal
-            const int cnt = C8 - cg0;
+            if (R >= RG) return false;
+            const int cg0 = (int)((((int64_t)R << lr) * BM) / ((int64_t)BN << lc));  // first column group that reaches the diagonal
+            const int cnt = CG - cg0;
             if (cnt <= 0) return false;
             if (mt < cnt) { Cg = cg0 + (int)mt; break; }
             mt -= cnt;
         }
     } else {
-        R = (int)(mt / C8);
-        Cg = (int)(mt % C8);
-        if (R >= R4) return false;
+        R = (int)(mt / CG);
+        Cg = (int)(mt % CG);
+        if (R >= RG) return false;
     }
-    ti = R * 4 + (tin >> 3);
-    tj = Cg * 8 + (tin & 7);
+    ti = (R << lr) + (tin >> lc);
+    tj = (Cg << lc) + (tin & ((1 << lc) - 1));
     // a symmetric job only needs tiles that reach the diagonal or lie above it
     return !(ti >= J.tiles_m || tj >= J.tiles_n || (sym && (int64_t)(tj + 1) * BN <= (int64_t)ti * BM));
 }
@@ -349,7 +352,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool K3M>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4)
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4 < 2 ? 2 : (WAVES_M * WAVES_N) / 4)
 gram_dma_kernel(GramArgs args) {
     using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, K3M>;
     constexpr int NACC = K3M ? 3 : 2;
@@ -733,6 +736,7 @@ __global__ void __launch_bounds__(256) gram32_small_kernel(GramArgs args) {
 struct Variant {
     const char* name;
     int bm, bn, threads, min_d;
+    int lr, lc;  // macro-tile shape (log2 block tiles): sized so that one XCD's resident workgroups form about one macro-tile
     size_t lds;
     const void* fn;
     void (*launch)(const GramArgs&, unsigned, hipStream_t);
@@ -748,7 +752,7 @@ void launch_variant(const GramArgs& args, unsigned blocks, hipStream_t stream) {
 #define QK_VARIANT(NAME, WM, WN, TM, TN, BK, K3M)                                                          \
     Variant {                                                                                              \
         NAME, GramCfg<WM, WN, TM, TN, BK, K3M>::BM, GramCfg<WM, WN, TM, TN, BK, K3M>::BN,                  \
-            GramCfg<WM, WN, TM, TN, BK, K3M>::THREADS, 1, GramCfg<WM, WN, TM, TN, BK, K3M>::LDS_BYTES,     \
+            GramCfg<WM, WN, TM, TN, BK, K3M>::THREADS, 1, 2, 3, GramCfg<WM, WN, TM, TN, BK, K3M>::LDS_BYTES, \
             (const void*)gram_kernel<WM, WN, TM, TN, BK, K3M>, launch_variant<WM, WN, TM, TN, BK, K3M>     \
     }
 
@@ -759,10 +763,10 @@ void launch_dma_variant(const GramArgs& args, unsigned blocks, hipStream_t strea
                        stream, args);
 }
 
-#define QK_DMA_VARIANT(NAME, WM, WN, TM, TN, K3M)                                                          \
+#define QK_DMA_VARIANT(NAME, WM, WN, TM, TN, K3M, LR, LC)                                                  \
     Variant {                                                                                              \
         NAME, GramDmaCfg<WM, WN, TM, TN, K3M>::BM, GramDmaCfg<WM, WN, TM, TN, K3M>::BN,                    \
-            GramDmaCfg<WM, WN, TM, TN, K3M>::THREADS, 16, GramDmaCfg<WM, WN, TM, TN, K3M>::LDS_BYTES,      \
+            GramDmaCfg<WM, WN, TM, TN, K3M>::THREADS, 16, LR, LC, GramDmaCfg<WM, WN, TM, TN, K3M>::LDS_BYTES, \
             (const void*)gram_dma_kernel<WM, WN, TM, TN, K3M>, launch_dma_variant<WM, WN, TM, TN, K3M>     \
     }
 
@@ -771,48 +775,80 @@ static const Variant kVariants[] = {
     QK_VARIANT("4m_128x128_w8_bk16", 2, 4, 4, 2, 16, false),
     QK_VARIANT("3m_96x128_w8_bk16", 2, 4, 3, 2, 16, true),
     QK_VARIANT("3m_128x96_w8_bk16", 4, 2, 2, 3, 16, true),
-    QK_DMA_VARIANT("dma3m_128x128_w8", 2, 4, 4, 2, true),
-    QK_DMA_VARIANT("dma3m_96x128_w8", 2, 4, 3, 2, true),   // BM = 96: 24 rows per wave
-    QK_DMA_VARIANT("dma4m_128x128_w8", 2, 4, 4, 2, false),
+    QK_DMA_VARIANT("dma3m_128x128_w8", 2, 4, 4, 2, true, 2, 3),
+    QK_DMA_VARIANT("dma3m_96x128_w8", 2, 4, 3, 2, true, 2, 3),   // BM = 96: 24 rows per wave
+    QK_DMA_VARIANT("dma4m_128x128_w8", 2, 4, 4, 2, false, 2, 3),
+    QK_DMA_VARIANT("dma3m_64x64_w4", 2, 2, 2, 2, true, 2, 3),    // two independent workgroups per CU
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 4;  // dma3m_128x128_w8: fastest measured (tools/gram_ab.py); variant 0 serves D < 16
+// Defaults, from in-process A/B runs (tools/gram_ab.py, tools/shard_ab.py):
+//   kBigVariant   dma3m_128x128_w8  one 8-wave workgroup per CU; best when a block streams >= 48 GiB of
+//                                   statevectors (the single-GPU N = 65536, n = 16 matrix: +1.3 %)
+//   kSmallVariant dma3m_64x64_w4    two independent 4-wave workgroups per CU: one keeps the matrix pipe busy
+//                                   while the other sits at its barrier, and small problems split into 4x as
+//                                   many tiles (N = 4096, n = 8: +34 %; one rank's share of the 8-GPU run: +5 %)
+// Variant 0 serves D < 16.
+constexpr int kBigVariant = 4, kSmallVariant = 7;
+constexpr int64_t kBigBytes = (int64_t)48 << 30;
 
-static int g_variant = -1;
+static int g_variant = -1;       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = choose per call
+static bool g_env_read = false;
 static bool g_attr_set[kNumVariants] = {false};
 
-static int pick_variant() {
-    if (g_variant >= 0) return g_variant;
-    g_variant = kDefaultVariant;
-    if (const char* e = std::getenv("QK_GRAM_VARIANT")) {
-        for (int v = 0; v < kNumVariants; ++v)
-            if (std::strcmp(e, kVariants[v].name) == 0) g_variant = v;
+static int pick_variant(const qk_gram_job* jobs, int n_jobs, int64_t D) {
+    if (!g_env_read) {
+        g_env_read = true;
+        if (const char* e = std::getenv("QK_GRAM_VARIANT"))
+            for (int v = 0; v < kNumVariants; ++v)
+                if (std::strcmp(e, kVariants[v].name) == 0) g_variant = v;
     }
-    return g_variant;
+    if (g_variant >= 0) return g_variant;
+    int64_t rows = 0;
+    if (jobs)
+        for (int k = 0; k < n_jobs && k < QK_GRAM_MAX_JOBS; ++k) rows = std::max(rows, std::max(jobs[k].ma, jobs[k].nb));
+    return rows * D * 16 >= kBigBytes ? kBigVariant : kSmallVariant;
 }
 
 }  // namespace qk
 
-// Development hook (not in the public header): select a kernel variant by name for A/B timing.
+// Development hooks (not in the public header).  qk_gram_set_variant: force a kernel variant by name for
+// A/B timing ("auto" or NULL: back to the per-call choice).  qk_gram_variant_for: the variant a block
+// of `rows` rows would run on (bench.py labels its roofline line with it).
 extern "C" int qk_gram_set_variant(const char* name) {
     using namespace qk;
+    g_env_read = true;
+    if (!name || std::strcmp(name, "auto") == 0) {
+        g_variant = -1;
+        return QK_OK;
+    }
     for (int v = 0; v < kNumVariants; ++v)
-        if (name && std::strcmp(name, kVariants[v].name) == 0) {
+        if (std::strcmp(name, kVariants[v].name) == 0) {
             g_variant = v;
             return QK_OK;
         }
     return fail(QK_ERR_INVALID, "qk_gram_set_variant: unknown variant");
 }
 
+extern "C" const char* qk_gram_variant_for(int64_t rows, int64_t D) {
+    using namespace qk;
+    qk_gram_job j;
+    std::memset(&j, 0, sizeof(j));
+    j.ma = j.nb = rows;
+    int vi = pick_variant(&j, 1, D);
+    if (D < kVariants[vi].min_d) vi = 0;
+    return kVariants[vi].name;
+}
 
 namespace qk {
 // validate the jobs and lay them out on the tile schedule of (bm x bn) block tiles
-static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int bm, int bn, const char* who, GramArgs& args,
-                           int64_t& blocks) {
+static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int bm, int bn, int lr, int lc, const char* who,
+                           GramArgs& args, int64_t& blocks) {
     if (!jobs || n_jobs < 1 || n_jobs > QK_GRAM_MAX_JOBS) return fail(QK_ERR_INVALID, std::string(who) + ": need 1..16 jobs");
     if (D < 1 || (D & (D - 1)) != 0) return fail(QK_ERR_INVALID, std::string(who) + ": D must be a power of two");
     std::memset(&args, 0, sizeof(args));
     args.D = D;
+    args.lr = lr;
+    args.lc = lc;
     blocks = 0;
     int nj = 0;
     for (int k = 0; k < n_jobs; ++k) {
@@ -835,18 +871,18 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
         d.tiles_m = (int32_t)((j.ma + bm - 1) / bm);
         d.tiles_n = (int32_t)((j.nb + bn - 1) / bn);
         d.block_begin = blocks;
-        const int C8 = (d.tiles_n + 7) / 8, R4 = (d.tiles_m + 3) / 4;
+        const int CG = (d.tiles_n + (1 << lc) - 1) >> lc, RG = (d.tiles_m + (1 << lr) - 1) >> lr;
         int64_t macros = 0;
         if (sym) {
-            for (int R = 0; R < R4; ++R) {
-                const int cnt = C8 - (R * bm) / (2 * bn);
+            for (int R = 0; R < RG; ++R) {
+                const int cnt = CG - (int)((((int64_t)R << lr) * bm) / ((int64_t)bn << lc));
                 if (cnt <= 0) break;
                 macros += cnt;
             }
         } else {
-            macros = (int64_t)R4 * C8;
+            macros = (int64_t)RG * CG;
         }
-        blocks += ((macros + 7) / 8) * 256;  // whole rounds of 8 macro-tiles keep block_begin % 256 == 0
+        blocks += ((macros + 7) / 8) * (8 << (lr + lc));  // whole rounds of 8 macro-tiles, one per XCD label
     }
     args.n_jobs = nj;
     if (blocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, std::string(who) + ": too many tiles; split the call");
@@ -856,12 +892,12 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
 
 extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
     using namespace qk;
-    int vi = pick_variant();
+    int vi = pick_variant(jobs, n_jobs, D);
     if (D < kVariants[vi].min_d) vi = 0;  // LDS-DMA tiles need 16 amplitudes per k-tile; tiny circuits use variant 0
     const Variant& V = kVariants[vi];
     GramArgs args;
     int64_t blocks = 0;
-    const int rc = build_gram_args(jobs, n_jobs, D, V.bm, V.bn, "qk_gram_jobs_dev", args, blocks);
+    const int rc = build_gram_args(jobs, n_jobs, D, V.bm, V.bn, V.lr, V.lc, "qk_gram_jobs_dev", args, blocks);
     if (rc) return rc;
     if (args.n_jobs == 0) return QK_OK;
     if (!g_attr_set[vi]) {
@@ -878,7 +914,7 @@ extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D
     using C = GramDmaCfg<2, 4, 4, 2, true>;
     GramArgs args;
     int64_t blocks = 0;
-    const int rc = build_gram_args(jobs, n_jobs, D, C::BM, C::BN, "qk_gram32_jobs_dev", args, blocks);
+    const int rc = build_gram_args(jobs, n_jobs, D, C::BM, C::BN, 2, 3, "qk_gram32_jobs_dev", args, blocks);
     if (rc) return rc;
     if (args.n_jobs == 0) return QK_OK;
     if (D < 32) {   // under 5 qubits: one launch per job, one thread per entry
