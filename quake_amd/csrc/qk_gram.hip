@@ -560,7 +560,7 @@ __device__ __forceinline__ void gram32_epilogue(v4f (&re)[TM][TN], v4f (&im)[TM]
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4)
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4 < 2 ? 2 : (WAVES_M * WAVES_N) / 4)
 gram32_dma_kernel(GramArgs args) {
     using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, true>;   // BK = 16 units = 32 amplitudes
     constexpr int KS = 4;
@@ -909,15 +909,35 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
     return QK_OK;
 }
 
-extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
-    using namespace qk;
-    using C = GramDmaCfg<2, 4, 4, 2, true>;
+namespace qk {
+template <int WM, int WN, int TM, int TN>
+static int launch_gram32(const qk_gram_job* jobs, int n_jobs, int64_t D, hipStream_t stream) {
+    using C = GramDmaCfg<WM, WN, TM, TN, true>;
     GramArgs args;
     int64_t blocks = 0;
     const int rc = build_gram_args(jobs, n_jobs, D, C::BM, C::BN, 2, 3, "qk_gram32_jobs_dev", args, blocks);
     if (rc) return rc;
     if (args.n_jobs == 0) return QK_OK;
-    if (D < 32) {   // under 5 qubits: one launch per job, one thread per entry
+    static bool attr_set = false;
+    if (!attr_set) {
+        QK_HIP(hipFuncSetAttribute((const void*)gram32_dma_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gram32_dma_kernel<WM, WN, TM, TN>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, stream, args);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+static int g_tile32 = 0;   // 0 = choose per call, 64 / 128 = forced (QK_GRAM32_TILE, A/B runs)
+}  // namespace qk
+
+extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
+    using namespace qk;
+    if (D >= 1 && D < 32 && (D & (D - 1)) == 0) {   // under 5 qubits: one launch per job, one thread per entry
+        GramArgs args;
+        int64_t blocks = 0;
+        const int rc = build_gram_args(jobs, n_jobs, D, 128, 128, 2, 3, "qk_gram32_jobs_dev", args, blocks);
+        if (rc) return rc;
         for (int k = 0; k < args.n_jobs; ++k) {
             GramArgs one;
             std::memset(&one, 0, sizeof(one));
@@ -931,16 +951,17 @@ extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D
         QK_HIP(hipGetLastError());
         return QK_OK;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        QK_HIP(hipFuncSetAttribute((const void*)gram32_dma_kernel<2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)C::LDS_BYTES));
-        attr_set = true;
+    static bool env_read = false;
+    if (!env_read) {
+        env_read = true;
+        if (const char* e = std::getenv("QK_GRAM32_TILE")) g_tile32 = std::atoi(e);
     }
-    hipLaunchKernelGGL((gram32_dma_kernel<2, 4, 4, 2>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
-                       (hipStream_t)stream, args);
-    QK_HIP(hipGetLastError());
-    return QK_OK;
+    int64_t rows = 0;
+    if (jobs)
+        for (int k = 0; k < n_jobs && k < QK_GRAM_MAX_JOBS; ++k) rows = std::max(rows, std::max(jobs[k].ma, jobs[k].nb));
+    const bool big = g_tile32 ? g_tile32 == 128 : rows * D * 8 >= kBigBytes / 2;   // measured crossover: between 16 and 32 GiB of complex64
+    return big ? launch_gram32<2, 4, 4, 2>(jobs, n_jobs, D, (hipStream_t)stream)
+               : launch_gram32<2, 2, 2, 2>(jobs, n_jobs, D, (hipStream_t)stream);
 }
 
 extern "C" int qk_gram_dev(const void* psi_x, int64_t N, const void* psi_y, int64_t M, int64_t D,
