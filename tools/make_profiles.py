@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Turn the databases tools/run_profiles.sh left under gpurun_out/r01/ into the committed summaries:
+profiles/r01_bench_default_kernel_trace.md, r01_bench_default.json, r01_pmc.md, r01_pmc_traffic.json,
+r01_configs.json."""
+import json, shutil, sqlite3, subprocess, sys
+O = "gpurun_out/r01/"
+with open("profiles/r01_bench_default_kernel_trace.md", "w") as f:
+    subprocess.check_call([sys.executable, "tools/rocpd_summary.py", O + "kt/kt_results.db"], stdout=f)
+shutil.copy(O + "bench.json", "profiles/r01_bench_default.json")
+shutil.copy(O + "configs.json", "profiles/r01_configs.json")
+
+def counters(p):
+    c = sqlite3.connect(O + p + "/p_results.db").cursor()
+    out = {}
+    for name, cn, did, val, dur in c.execute("select kernel_name, counter_name, dispatch_id, value, duration from counters_collection order by dispatch_id"):
+        k = "gram" if "gram" in name else ("sim" if "sim_pass" in name else None)
+        if k: out.setdefault((k, did), {"dur_ns": dur})[cn] = val
+    return out
+A, B, C = counters("pmcA"), counters("pmcB"), counters("pmcC")
+first = lambda d, k: [v for (kk, _), v in d.items() if kk == k][0]
+gA, gB, gC, sA, sB = first(A, "gram"), first(B, "gram"), first(C, "gram"), first(A, "sim"), first(B, "sim")
+fetch, write = gA["FETCH_SIZE"] * 1024 * 2, gB["WRITE_SIZE"] * 1024
+N = D = 65536
+alg = N * D * 16 + N * N * 8
+cyc = gC["GRBM_GUI_ACTIVE"] / 8
+t = gC["dur_ns"] * 1e-9
+mfma_flops = gC["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512
+util = gC["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024)
+md = f"""# r01 PMC passes: default bench (N=65536, 16 qubits, zz r=1, 1 GPU), one launch each
+
+Command per pass (tools/run_profiles.sh): `rocprofv3 --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`
+(separate runs for FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set, no trace flags, as MI355X_MICROARCH.md prescribes).
+Summaries made by tools/make_profiles.py.
+
+## qk::gram_dma_kernel<2,4,4,2,true> (one launch, {t:.3f} s on this box)
+
+| quantity | raw counter | derived |
+|---|---|---|
+| FETCH_SIZE | {gA['FETCH_SIZE']:.6g} KiB | x1024 x2 (gfx950: 16-B/lane loads are tallied at half) = **{fetch:.4g} B** read at the memory side of L2 = {fetch/gA['dur_ns']:.0f} GB/s |
+| WRITE_SIZE | {gB['WRITE_SIZE']:.6g} KiB | x1024 = **{write:.4g} B** (K is N*N*8 = {N*N*8:.4g} B) |
+| compulsory traffic | | Psi once + K once = {alg:.4g} B; the kernel re-reads Psi tiles {fetch/(N*D*16):.0f}x (tile reuse is bounded by L2: the 4x8 macro-tile schedule keeps it at {fetch/gA['dur_ns']/1e3:.2f} TB/s, far under the 8 TB/s HBM roof -- the kernel is MFMA-bound) |
+| GRBM_GUI_ACTIVE | {gC['GRBM_GUI_ACTIVE']:.6g} (sum over 8 XCDs) | {cyc:.4g} cycles = **{cyc/t/1e9:.3f} GHz** sustained shader clock on this box |
+| SQ_INSTS_VALU_MFMA_MOPS_F64 | {gC['SQ_INSTS_VALU_MFMA_MOPS_F64']:.6g} (x512 flops) | **{mfma_flops:.4g} hardware MFMA flops** = 6*D per computed entry (3M product); {mfma_flops/t/1e12:.1f} TFLOP/s |
+| SQ_VALU_MFMA_BUSY_CYCLES | {gC['SQ_VALU_MFMA_BUSY_CYCLES']:.6g} | / (cycles x 1024 SIMDs) = **{util*100:.1f}% MFMA pipe busy** |
+| SQ_WAVE_CYCLES / SQ_BUSY_CYCLES | {gC['SQ_WAVE_CYCLES']:.4g} / {gC['SQ_BUSY_CYCLES']:.4g} | |
+| SQ_WAIT_INST_ANY / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY | {gC['SQ_WAIT_INST_ANY']:.4g} / {gC['SQ_WAIT_ANY']:.4g} / {gC['SQ_ACTIVE_INST_ANY']:.4g} | issue-stall (MFMA pipe back-pressure) {gC['SQ_WAIT_INST_ANY']/gC['SQ_WAVE_CYCLES']*100:.0f}% of wave cycles, parked on waitcnt/barrier {gC['SQ_WAIT_ANY']/gC['SQ_WAVE_CYCLES']*100:.0f}% |
+
+The MFMA pipe is busy {util*100:.1f}% of the cycles the GPU was active.  The peak figure of 78.6 TFLOP/s assumes
+2.4 GHz; this box held {cyc/t/1e9:.2f} GHz under the kernel (boxes of the pool differ: 2.09 - 2.38 GHz seen, the
+same launch takes 12.03 s on a 2.38 GHz box; cycle counts agree to 1%).  Cycle for cycle the kernel is at
+{util*100:.0f}% of the FP64 matrix pipe and, because the 3-multiplication complex product needs 6 instead of 8
+real flops per complex multiply-add, delivers {8/6*util*100:.0f}% of the pipe's peak in algorithmic (8*D per entry) flops.
+
+## qk::sim_pass_kernel inside the same run (N=65536 samples, one write-only pass)
+
+| quantity | value |
+|---|---|
+| duration | {sA['dur_ns']/1e6:.2f} ms |
+| WRITE_SIZE | {sB['WRITE_SIZE']:.6g} KiB = {sB['WRITE_SIZE']*1024:.4g} B = exactly N * 2^16 * 16 B (the algorithmic bytes) -> {sB['WRITE_SIZE']*1024/sB['dur_ns']:.0f} GB/s |
+| FETCH_SIZE | {sA['FETCH_SIZE']:.6g} KiB (feature rows and tables only: the pass loads no amplitudes) |
+
+## simulator alone: `tools/sim_bench.py --qubits 16 --maps zz_r1 zz_r2` (N=4096, 4 GiB of Psi per launch)
+
+Per dispatch, in launch order: 4x zz_r1 (one pass), then zz_r2 = pass 1, pass 2 alternating.
+
+| dispatch | ms | WRITE_SIZE KiB | FETCH_SIZE KiB (x2 for bytes) | HBM GB/s (write + 2*fetch) | SQ_INSTS_LDS | SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE | SQ_INSTS_VALU | SQ_ACTIVE_INST_LDS |
+|---|---|---|---|---|---|---|---|---|
+"""
+Dd, E, F = counters("pmcD"), counters("pmcE"), counters("pmcF")
+for (k, d), v in sorted(Dd.items(), key=lambda kv: kv[0][1]):
+    w, f = F[(k, d)]["WRITE_SIZE"], E[(k, d)]["FETCH_SIZE"]
+    md += (f"| {d} | {v['dur_ns']/1e6:.3f} | {w:.6g} | {f:.6g} | {(w*1024+2*f*1024)/v['dur_ns']:.0f} | {v['SQ_INSTS_LDS']:.4g} | "
+           f"{v['SQ_LDS_BANK_CONFLICT']:.4g} / {v['SQ_LDS_IDX_ACTIVE']:.4g} = {v['SQ_LDS_BANK_CONFLICT']/v['SQ_LDS_IDX_ACTIVE']*100:.1f}% | "
+           f"{v['SQ_INSTS_VALU']:.4g} | {v['SQ_ACTIVE_INST_LDS']:.4g} |\n")
+md += """
+Reading: the single-pass zz r=1 launch writes exactly its algorithmic bytes and reads only tables.  The passes
+are bound by FP64 VALU issue (angle programs, phase tables, butterflies), not by HBM or LDS: LDS bank
+conflicts are a few percent of LDS-active cycles in every pass (the butterflies on the lowest qubits use an
+XOR-swizzled register mapping).
+"""
+open("profiles/r01_pmc.md", "w").write(md)
+json.dump({"workload": {"rows": 65536, "qubits": 16, "repeats": 1, "gpus": 1},
+           "gram_hbm_bytes_per_launch": fetch + write, "gram_fetch_bytes": fetch, "gram_write_bytes": write,
+           "source": "profiles/r01_pmc.md: FETCH_SIZE KiB x1024 x2 (gfx950 correction for 16-B/lane loads) + WRITE_SIZE KiB x1024, separate --pmc passes"},
+          open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+print(md[-2500:])

@@ -2,7 +2,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r01
 rm -rf $O && mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --test-rows 0 > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmcA -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmcA.json 2> $O/pmcA.err
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmcB -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmcB.json 2> $O/pmcB.err
