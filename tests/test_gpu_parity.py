@@ -203,6 +203,12 @@ def test_api_shapes_and_errors():
     assert one.shape == (1, 1) and one[0, 0] == 1.0
     cross = k.evaluate(np.array([0.1, 0.2, 0.3]), np.array([[0.1, 0.2, 0.3], [0.3, 0.2, 0.1]]))
     assert cross.shape == (1, 2) and abs(cross[0, 0] - 1.0) < 1e-14
+    # empty inputs: empty outputs of the right shape (also for the projected kernel and FP32 mode)
+    assert k.evaluate(np.zeros((0, n))).shape == (0, 0)
+    assert k.evaluate(np.zeros((4, n)), np.zeros((0, n))).shape == (4, 0)
+    assert k.evaluate(np.zeros((0, n)), np.zeros((3, n))).shape == (0, 3)
+    assert HipFidelityKernel(fm.z_featuremap(x, n), precision="single").evaluate(np.zeros((0, n))).shape == (0, 0)
+    assert projected_quantum_kernel(fm.z_featuremap(x, n), np.zeros((0, n)), 1.0).shape == (0, 0)
     # float32 and integer inputs widen exactly
     Xf = synth_X(9, n, "scaled", 3).astype(np.float32)
     assert np.array_equal(k.evaluate(Xf), k.evaluate(Xf.astype(np.float64)))
