@@ -16,7 +16,8 @@ ap.add_argument("--grams", type=int, default=150)
 ap.add_argument("--seed", type=int, default=0)
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
-worst = 0.0
+worst = worst_rdm = 0.0
+worst_rdm_case = None
 for t in range(a.circuits):
     n = int(rng.integers(1, 16))
     F = int(rng.integers(1, 6))
@@ -45,10 +46,19 @@ for t in range(a.circuits):
     N = int(rng.integers(1, 6 if n > 12 else 40))
     X = rng.uniform(-1.5, 1.5, size=(N, c.num_parameters))
     got = HipFidelityKernel(c).statevectors(X)
-    err = float(np.abs(got - psi_from_compiled(c, X)).max())
+    ref = psi_from_compiled(c, X)
+    err = float(np.abs(got - ref).max())
     worst = max(worst, err)
     assert err < 1e-12, ("circuit", t, n, err)
-print("circuits ok, worst |dpsi| =", worst, flush=True)
+    # reduced density matrices: fused with the simulation when the circuit is one LDS-resident pass
+    r = O.rdm1(ref, n)
+    want = np.stack([r[..., 0, 0].real, r[..., 1, 1].real, r[..., 0, 1].real, r[..., 0, 1].imag], axis=-1)
+    rd = qdev.simulate_rdm1(qdev.DeviceCircuit(c), torch.from_numpy(X).cuda()).cpu().numpy()
+    e2 = float(np.abs(rd - want).max())
+    if e2 > worst_rdm:
+        worst_rdm, worst_rdm_case = e2, (t, n, N, float(np.abs(ref).max()), float(np.abs(np.linalg.norm(ref, axis=1) - 1).max()))
+    assert e2 < 1e-12, ("rdm", t, n, e2)
+print("circuits ok, worst |dpsi| =", worst, "worst |drdm| =", worst_rdm, worst_rdm_case, flush=True)
 
 worst64 = worst32 = 0.0
 for t in range(a.grams):
