@@ -194,7 +194,10 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         Pass ps;
         ps.L = Lmax;
         ps.first = (pi == 0);
-        ps.lgT = ps.L >= 13 ? 9 : (ps.L >= 9 ? 8 : std::max(6, ps.L - 1));
+        // Workgroup size.  The simulator's occupancy is bound by registers (3 waves per SIMD), so what
+        // counts is work per wave: one wave per sample up to 9 qubits (the barriers of a one-wave
+        // workgroup cost nothing and 12 samples are in flight per CU), two at 10 (measured on gfx950).
+        ps.lgT = ps.L >= 13 ? 9 : (ps.L >= 11 ? 8 : (ps.L == 10 ? 7 : 6));
         ps.h = ps.L <= 6 ? ps.L : 6;    // 64 columns = one wavefront; <= kMaxRowBits row bits
         ps.maxg = ps.L >= 12 ? 3 : 2;   // radix-8 sweeps need the 512-thread / 256-VGPR kernel
         ps.phys = d.S;

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -14,6 +15,18 @@ namespace qk {
 // ---- error plumbing -------------------------------------------------------
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+
+// hipFuncSetAttribute applies to the current device only, so "done once" is kept per device (one
+// bit each; two threads that race both set the attribute, which is harmless).
+struct DeviceOnce {
+    std::atomic<uint64_t> seen{0};
+    static uint64_t bit() {
+        int dev = 0;
+        return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    }
+    bool pending() const { const uint64_t b = bit(); return b == 0 || !(seen.load() & b); }
+    void done() { seen.fetch_or(bit()); }
+};
 
 #define QK_HIP(expr)                                                                       \
     do {                                                                                   \

@@ -793,7 +793,7 @@ constexpr int64_t kBigBytes = (int64_t)48 << 30;
 
 static int g_variant = -1;       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = choose per call
 static bool g_env_read = false;
-static bool g_attr_set[kNumVariants] = {false};
+static DeviceOnce g_attr_set[kNumVariants];
 
 static int pick_variant(const qk_gram_job* jobs, int n_jobs, int64_t D) {
     if (!g_env_read) {
@@ -900,9 +900,9 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
     const int rc = build_gram_args(jobs, n_jobs, D, V.bm, V.bn, V.lr, V.lc, "qk_gram_jobs_dev", args, blocks);
     if (rc) return rc;
     if (args.n_jobs == 0) return QK_OK;
-    if (!g_attr_set[vi]) {
+    if (g_attr_set[vi].pending()) {
         QK_HIP(hipFuncSetAttribute(V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds));
-        g_attr_set[vi] = true;
+        g_attr_set[vi].done();
     }
     V.launch(args, (unsigned)blocks, (hipStream_t)stream);
     QK_HIP(hipGetLastError());
@@ -918,11 +918,11 @@ static int launch_gram32(const qk_gram_job* jobs, int n_jobs, int64_t D, hipStre
     const int rc = build_gram_args(jobs, n_jobs, D, C::BM, C::BN, 2, 3, "qk_gram32_jobs_dev", args, blocks);
     if (rc) return rc;
     if (args.n_jobs == 0) return QK_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.pending()) {
         QK_HIP(hipFuncSetAttribute((const void*)gram32_dma_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)C::LDS_BYTES));
-        attr_set = true;
+        attr_set.done();
     }
     hipLaunchKernelGGL((gram32_dma_kernel<WM, WN, TM, TN>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, stream, args);
     QK_HIP(hipGetLastError());

@@ -170,10 +170,10 @@ extern "C" int qk_rdm1_dev(const void* psi_dev, int64_t N, int n_qubits, double*
     if (N == 0) return QK_OK;
     if (n_qubits <= RDM_MAXQ) {
         const size_t lds = ((size_t)16 << n_qubits) + (size_t)RDM_SLOTS * (RDM_THREADS / 64) * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DeviceOnce attr_set;
+        if (attr_set.pending()) {
             QK_HIP(hipFuncSetAttribute((const void*)rdm1_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            attr_set.done();
         }
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
         const int64_t blocks = std::min<int64_t>(N, (int64_t)256 * per_cu);
@@ -201,10 +201,10 @@ extern "C" int qk_pqk_dev(const double* rdm_x, int64_t N, const double* rdm_y, i
     if (nblocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, "qk_pqk_dev: too many tiles");
     const size_t lds = (size_t)2 * PT * n_qubits * 4 * sizeof(double);
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DeviceOnce attr_set;
+        if (attr_set.pending()) {
             QK_HIP(hipFuncSetAttribute((const void*)pqk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            attr_set.done();
         }
     }
     hipLaunchKernelGGL(pqk_kernel, dim3((unsigned)nblocks), dim3(256), lds, (hipStream_t)stream, rdm_x, N, rdm_y, M,

@@ -281,19 +281,29 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         for (int k = tid; k < a.n_prog; k += T) s_prog[k] = a.prog[k];
         for (int k = tid; k < a.n_consts; k += T) s_const[k] = a.consts[k];
     }
-    if ((int64_t)blockIdx.x < a.n_items)
-        for (int t = tid; t < a.n_params; t += T) xbuf[t] = a.X[((int64_t)blockIdx.x >> a.nlive) * a.ldx + t];
+    // Persistent workgroups: each owns a contiguous range of (sample, chunk) items, so the launch
+    // cost is paid once per CU slot and the chunks of one sample follow each other: the angle
+    // programs (the longest dependent chain of an item) run once per sample, not once per chunk.
+    const int64_t per_wg = (a.n_items + gridDim.x - 1) / gridDim.x;
+    const int64_t item_begin = (int64_t)blockIdx.x * per_wg;
+    const int64_t item_end = item_begin + per_wg < a.n_items ? item_begin + per_wg : a.n_items;
+    if (item_begin < item_end)
+        for (int t = tid; t < a.n_params; t += T) xbuf[t] = a.X[(item_begin >> a.nlive) * a.ldx + t];
     __syncthreads();
 
-    // Persistent workgroups: each walks (sample, chunk) items with a grid stride, so the launch cost
-    // is paid once per CU slot.  Chunks whose amplitudes are all still zero after the pass (and a
-    // later pass knows) are not items at all.  In steady state the only vector-memory traffic of a
-    // first pass is the store of the chunk and the prefetch of the next feature row, so the stores
-    // of one item drain while the next is computed.
+    // Chunks whose amplitudes are all still zero after the pass (and a later pass knows) are not
+    // items at all.  In steady state the only vector-memory traffic of a first pass is the store of
+    // the chunk and the prefetch of the next feature row, so the stores of one item drain while the
+    // next is computed.
+    // A diagonal stage right after the hoisted first gates (every Z / ZZ map) takes the product
+    // state as two more factors of its tables: the state is written once, phases included.
+    const bool fuse_init = a.first && a.n_init > 0 && a.n_init < a.n_stage && a.stages[a.n_init].kind == ST_DIAG;
     int par = 0;
-    for (int64_t item = blockIdx.x; item < a.n_items; item += gridDim.x, par ^= 1) {
-        const int64_t next = item + gridDim.x;
-        const bool have_next = next < a.n_items && tid < a.n_params;
+    int64_t angles_of = -1;     // the sample whose (cos, sin) values sit in rt / mat
+    for (int64_t item = item_begin; item < item_end; ++item) {
+        const int64_t next = item + 1;
+        const bool fetch = next < item_end && (next >> a.nlive) != (item >> a.nlive);
+        const bool have_next = fetch && tid < a.n_params;
         double xnext = 0.0;
         if (have_next) xnext = a.X[(next >> a.nlive) * a.ldx + tid];   // in flight until the end of the item
         uint32_t chunk = 0;
@@ -319,8 +329,11 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             }
         }
         // ---- per-sample gate angles -> (cos, sin) into their term or matrix ---------------
-        if (a.staged) run_angle_programs(s_expr, s_prog, s_const, xrow, a.n_expr, rt, mat, tid, T);
-        else run_angle_programs(a.exprs, a.prog, a.consts, xrow, a.n_expr, rt, mat, tid, T);
+        if (sample != angles_of) {
+            if (a.staged) run_angle_programs(s_expr, s_prog, s_const, xrow, a.n_expr, rt, mat, tid, T);
+            else run_angle_programs(a.exprs, a.prog, a.consts, xrow, a.n_expr, rt, mat, tid, T);
+            angles_of = sample;
+        }
         __syncthreads();
 
         // ---- first pass: the product state of the hoisted first gates -----------------------
@@ -344,8 +357,10 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 (is_lo ? tlo[j] : thi[j - nlo]) = f;
             }
             __syncthreads();
-            for (uint32_t l = tid; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
-            __syncthreads();
+            if (!fuse_init) {
+                for (uint32_t l = tid; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
+                __syncthreads();
+            }
         }
 
         // ---- stages -----------------------------------------------------------------------
@@ -364,6 +379,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 const int nrb = L - h;
                 const uint32_t nlo = 1u << h, nhi = 1u << nrb;
                 const uint32_t n_rat = st.nX ? (nlo * (uint32_t)nrb) : 0u;
+                const bool fused = fuse_init && s == a.n_init;   // tlo / thi hold the product state's factors
                 // work items: the ratio table first (64 columns: a wavefront shares its row bit, so
                 // the term ranges are scalar reads), then the column and the row tables
                 for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
@@ -384,19 +400,23 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         const uint32_t c = j - n_rat, w = whi | c;
                         for (int k = 0; k < st.nLo; ++k) apply_term(tl[k], w, fr, fi);
                         for (int k = 0; k < st.nX; ++k) apply_term(tx[k], w, fr, fi);   // X(0, c)
-                        tlo[c] = make_double2(fr, fi);
+                        tlo[c] = fused ? cmul(tlo[c], make_double2(fr, fi)) : make_double2(fr, fi);
                     } else {
                         const uint32_t r = j - n_rat - nlo, w = whi | (r << h);
                         for (int k = 0; k < st.nHi; ++k) apply_term(th[k], w, fr, fi);
-                        thi[r] = make_double2(fr, fi);
+                        thi[r] = fused ? cmul(thi[r], make_double2(fr, fi)) : make_double2(fr, fi);
                     }
                 }
                 __syncthreads();
                 if (st.nX == 0) {
-                    for (uint32_t l = tid; l < nloc; l += T) {
-                        const double2 f0 = tlo[l & (nlo - 1u)], f1 = thi[l >> h];
-                        const double2 v = state[l];
-                        state[l] = cmul(v, cmul(f0, f1));
+                    if (fused) {
+                        for (uint32_t l = tid; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
+                    } else {
+                        for (uint32_t l = tid; l < nloc; l += T) {
+                            const double2 f0 = tlo[l & (nlo - 1u)], f1 = thi[l >> h];
+                            const double2 v = state[l];
+                            state[l] = cmul(v, cmul(f0, f1));
+                        }
                     }
                 } else {
                     // h == 6: lane = column; the wave owns 2^kb consecutive rows
@@ -422,7 +442,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         const uint32_t r = r0 | g;
                         const double2 f = cmul(X, thi[r]);
                         const uint32_t l = (r << h) | c;
-                        state[l] = cmul(state[l], f);
+                        state[l] = fused ? f : cmul(state[l], f);
                     }
                 }
             } else if (st.kind == ST_U1) {
@@ -476,7 +496,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         }
         // ---- write back (amplitudes that are still known-zero are left to the next pass) ------
         if (have_next) xbuf[(par ^ 1) * xs + tid] = xnext;
-        if (next < a.n_items)   // more features than threads: the rest without the register detour
+        if (fetch)   // more features than threads: the rest without the register detour
             for (int t = tid + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
         __syncthreads();
         if constexpr (RDM) rdm1_from_lds(state, L, s_red, a.rdm + sample * (L * 4), tid, T);
@@ -493,6 +513,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         // LDS is reused by the next item.  A bare barrier: every wave's LDS reads have returned
         // before it issued its stores, and the stores themselves need not have landed.
         __builtin_amdgcn_s_barrier();
+        if (fetch) par ^= 1;
     }
 }
 
@@ -542,13 +563,13 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     int rc = upload_circuit(c);
     if (rc) return rc;
     const int n = c.n_qubits;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.pending()) {
         QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     for (size_t pi = 0; pi < c.passes.size(); ++pi) {
         const Pass& ps = c.passes[pi];
