@@ -4,8 +4,10 @@ fidelity kernel (BASELINE.json metric; configs[4], which fits one MI355X: Psi 64
 K 32 GiB of 288 GB).
 
 One step = the whole hot path over one batch of synthetic inputs that already sit in
-HBM: simulate the rank's statevector shard -> (N>1: all-gather Psi over RCCL) ->
-FP64-MFMA Gram of the rank's share -> (N>1: hand mirrored blocks to their owners).
+HBM: simulate the statevectors (N>1: every rank simulates all rows itself -- ~30 ms, cheaper
+than receiving them over xGMI; --psi gather shards the simulation and all-gathers Psi over
+RCCL instead) -> FP64-MFMA Gram of the rank's share of the upper triangle -> (N>1: hand the
+mirrored blocks to the ranks that own those rows, point to point).
 N GPUs split the SAME N=65536 problem (strong scaling); `value` is delivered entries
 (N^2, both triangles written) per second of max-over-ranks wall time.
 
@@ -47,6 +49,9 @@ def parse():
                     help="single = complex64 statevectors + FP32-MFMA Gram stage (optional mode, 1e-5 tolerance)")
     ap.add_argument("--workload", choices=["fidelity", "pqk"], default="fidelity",
                     help="pqk = BASELINE configs[3]: projected kernel, N=32768, 12 qubits (use --rows/--qubits to change)")
+    ap.add_argument("--psi", choices=["replicate", "gather"], default="replicate",
+                    help="N>1: every rank simulates all rows (default, no collective on the data path), or "
+                         "simulates its own rows and all-gathers the statevector shards over RCCL")
     ap.add_argument("--test-rows", type=int, default=-1,
                     help="also time the test x train block of configs[4] after the timed steps (default: N/4 at N=1, 0 = off)")
     return ap.parse_args()
@@ -229,7 +234,10 @@ def main():
     rng = np.random.default_rng(1005)
     lo, hi = -np.pi / 2 + 1e-5, np.pi / 2 - 1e-5
     X_host = rng.uniform(lo, hi, size=(N, n))
-    X = torch.from_numpy(X_host[r0:r1].copy()).to(dev)
+    # N > 1: every rank simulates all N rows (deterministic, ~30 ms) instead of receiving 7/8 of Psi
+    # over xGMI; --psi gather simulates the rank's rows only and all-gathers the shards over RCCL
+    gather = world > 1 and a.psi == "gather"
+    X = torch.from_numpy(X_host[r0:r1].copy() if gather else X_host).to(dev)
 
     circ = qdev.DeviceCircuit(fm.zz_featuremap(ParameterVector("x", n), n, a.repeats))
     single = a.precision == "single"
@@ -249,10 +257,10 @@ def main():
     def step(timed):
         t = timer if timed else None
         if t: t("sim_begin")
-        circ.simulate(X, out=psi[r0:r1])
+        circ.simulate(X, out=psi[r0:r1] if gather else psi)
         if t: t("sim_end")
         work = None
-        if world > 1:
+        if gather:
             # in-place all-gather of the shards (float64 views: RCCL has no complex dtype)
             work = dist.all_gather_into_tensor(psi_real, psi_real[r0:r1], async_op=True)
         sg.compute(psi, K, gather_work=work, timer=t)
@@ -319,6 +327,7 @@ def main():
                 "workload": f"{n}-qubit zz_featuremap r={a.repeats} fidelity kernel, N={N} train x train "
                             f"(BASELINE configs[4]), symmetric: N(N+1)/2 entries computed, N^2 delivered",
                 "rows": N, "qubits": n, "parallelism": f"row-block x{world}",
+                "psi": "single GPU" if world == 1 else ("all-gather of shards" if gather else "simulated on every rank"),
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK, "unit": "TFLOP/s",

@@ -3,9 +3,13 @@
 One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI).
 Rank g owns rows ``[g*N/G, (g+1)*N/G)``:
 
-1. it simulates the statevectors of its rows (no exchange);
-2. ONE data exchange replicates the compact statevector matrix: an all-gather of
-   the Psi shards (the only collective on the path);
+1./2. every rank needs all N statevectors.  The feature matrix X is tiny and the
+   simulator is deterministic, so the default is that every rank simulates ALL rows
+   itself (16 qubits, N = 65536: ~30 ms, against >= 160 ms to move the other ranks'
+   56 GiB over xGMI) -- no collective on the data path.  For circuits deep enough
+   that simulation costs more than the transfer, a rank simulates its own rows only
+   and an all-gather of the Psi shards replicates them, overlapped with the diagonal
+   block (``gather_work``);
 3. it computes its share of the symmetric matrix.  Computing the full row block
    would do every off-diagonal entry twice across the node, so the blocks are dealt
    out circulantly instead: rank g computes its diagonal block (upper triangle),
@@ -136,13 +140,17 @@ class ShardedGram:
         sends = list(self._stage["send"])
         diag = [t for t in self.tasks if t.symmetric]
         rest = [t for t in self.tasks if not t.symmetric]
-        # the diagonal block only needs the local shard: it overlaps the all-gather
         if timer: timer("gram_begin")
-        self._gram_jobs(self._jobs(psi_full, K_block, diag, sends), self.D)
-        if gather_work is not None:
+        if gather_work is None:
+            # every row of psi_full is already valid (each rank simulated all of them, or world == 1):
+            # one launch over all blocks, so the tail of one block overlaps the start of the next
+            self._gram_jobs(self._jobs(psi_full, K_block, diag + rest, sends), self.D)
+        else:
+            # the diagonal block only needs the local shard: it overlaps the all-gather
+            self._gram_jobs(self._jobs(psi_full, K_block, diag, sends), self.D)
             gather_work.wait()
-        if rest:
-            self._gram_jobs(self._jobs(psi_full, K_block, rest, sends), self.D)
+            if rest:
+                self._gram_jobs(self._jobs(psi_full, K_block, rest, sends), self.D)
         if timer: timer("gram_end")
         if self.world == 1:
             return K_block

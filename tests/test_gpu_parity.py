@@ -260,6 +260,25 @@ def test_gram_raw_layout_asymmetric():
         assert (S[0] == -1).all() and (S[:, :2] == -1).all() and (S[N + 1:] == -1).all() and (S[:, N + 2:] == -1).all()
 
 
+def test_projected_kernel_distance_scales():
+    """The pairwise kernel's square root is hand-rolled (hardware rsq seed + refinement): rows that
+    differ by 1 down to 1e-12 per component, against a long-double evaluation of the same formula
+    (reference genetic_v3.py:793-805)."""
+    import torch
+    from quake_amd import device as dev
+    rng = np.random.default_rng(5)
+    N, n = 700, 6
+    for scale in (1.0, 1e-3, 1e-6, 1e-9, 1e-12, 0.0):
+        r = rng.uniform(-1, 1, size=(1, n, 4)) + scale * rng.uniform(-1, 1, size=(N, n, 4))
+        K = dev.pqk(torch.from_numpy(r).cuda(), None, 1.0).cpu().numpy()
+        d = (r[:, None] - r[None]).astype(np.longdouble)
+        fro = np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2 + 2 * (d[..., 2] ** 2 + d[..., 3] ** 2))
+        ref = np.exp(-fro.sum(-1)).astype(np.float64)
+        np.fill_diagonal(ref, 1.0)
+        assert np.abs(K - ref).max() < 1e-15, scale
+        assert np.array_equal(K, K.T)
+
+
 @pytest.mark.parametrize("precision,tol", [("double", TOL_K), ("single", 1e-5)])
 def test_host_path_row_bands(precision, tol):
     """Above 2048 rows the host entry point computes K in row bands and copies each band back while

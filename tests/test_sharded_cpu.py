@@ -59,7 +59,7 @@ def _cpu_gram_jobs(jobs, D):
             j["KT"].copy_(torch.from_numpy(np.ascontiguousarray(K.T)))
 
 
-def _worker(rank, world, port, N, n):
+def _worker(rank, world, port, N, n, replicate=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -68,10 +68,14 @@ def _worker(rank, world, port, N, n):
         ops = O.zz_featuremap(n, 1)
         r0, r1 = sharded.row_range(rank, world, N)
         D = 1 << n
-        psi_full = torch.zeros((N, D), dtype=torch.complex128)
-        local = torch.from_numpy(O.statevectors(ops, n, X[r0:r1]))
-        psi_full[r0:r1] = local
-        work = dist.all_gather_into_tensor(psi_full, local, async_op=True)
+        if replicate:   # bench.py's default: every rank simulates all rows, no collective before the Gram
+            psi_full = torch.from_numpy(O.statevectors(ops, n, X))
+            work = None
+        else:
+            psi_full = torch.zeros((N, D), dtype=torch.complex128)
+            local = torch.from_numpy(O.statevectors(ops, n, X[r0:r1]))
+            psi_full[r0:r1] = local
+            work = dist.all_gather_into_tensor(psi_full, local, async_op=True)
         sg = sharded.ShardedGram(N, D, rank, world, gram_jobs=_cpu_gram_jobs)
         K_block = torch.full((r1 - r0, N), -1.0, dtype=torch.float64)
         sg.compute(psi_full, K_block, gather_work=work)
@@ -91,6 +95,11 @@ def _free_port():
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_gram_over_gloo(world):
     mp.spawn(_worker, args=(world, _free_port(), 8 * world, 4), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gram_replicated_psi_over_gloo(world):
+    mp.spawn(_worker, args=(world, _free_port(), 8 * world, 4, True), nprocs=world, join=True)
 
 
 def _cpu_pqk(rdm_x, rdm_y, gamma, out):
