@@ -147,6 +147,27 @@ def test_golden_pins_on_gpu(pins, data8, data_labels):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("cols", ["torino8", "all18"])
+def test_config1_bundled_dataset(cols, data_cv, data8, data_labels):
+    """BASELINE configs[0], the reference's own CPU-runnable case: the bundled 100-row dataset through
+    zz_featuremap r = 1 -- on the 8 columns of examples/torino_run.py:64 (8 qubits) and on all 18
+    columns (18 qubits: two simulator passes, statevectors of 4 MiB)."""
+    X = (data8 if cols == "torino8" else data_cv[:48]).astype(np.float64)   # 18 qubits: the oracle takes ~0.4 s per row
+    y = data_labels[:X.shape[0]]
+    n = X.shape[1]
+    circ, oops, _ = map_pairs(n, 1)["zz"]
+    K = HipFidelityKernel(circ).evaluate(X)
+    Kref = O.evaluate(oops, n, X)
+    assert np.abs(K - Kref).max() < TOL_K
+    assert np.array_equal(K, K.T) and (np.diag(K) == 1.0).all()
+    a = SVC(kernel="precomputed", C=1).fit(K, y).predict(K)
+    b = SVC(kernel="precomputed", C=1).fit(Kref, y).predict(Kref)
+    assert np.array_equal(a, b)
+    sa = cross_val_score(SVC(kernel="precomputed", C=1), K, y, cv=5)
+    sb = cross_val_score(SVC(kernel="precomputed", C=1), Kref, y, cv=5)
+    assert np.array_equal(sa, sb)
+
+
 @pytest.mark.parametrize("variant,Q", [("v3", 4), ("v5", 10)])
 def test_genome_circuits(variant, Q):
     """Config 3 in miniature: heterogeneous genomes, every gate of the alphabet."""
