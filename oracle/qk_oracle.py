@@ -46,17 +46,20 @@ def _g(name, qubits, fn=None, used=()):
     return (name, tuple(qubits), fn, tuple(used))
 
 
-def zz_featuremap(n, repeats=1):
-    """reference quantum_featuremaps.py:66-81"""
+def zz_featuremap(n, repeats=1, entanglement="linear"):
+    """reference quantum_featuremaps.py:66-81 (linear); "full" = the Qiskit library default pair list
+    (itertools.combinations order), which no reference run uses"""
+    pairs = [(q, q + 1) for q in range(n - 1)] if entanglement == "linear" else \
+        [(i, j) for i in range(n) for j in range(i + 1, n)]
     ops = []
     for _ in range(repeats):
         for q in range(n):
             ops.append(_g("h", [q]))
             ops.append(_g("p", [q], (lambda P, q=q: 2 * P[:, q]), [q]))
-        for q in range(n - 1):
-            ops.append(_g("cx", [q, q + 1]))
-            ops.append(_g("p", [q + 1], (lambda P, q=q: 2 * (PI - P[:, q]) * (PI - P[:, q + 1])), [q, q + 1]))
-            ops.append(_g("cx", [q, q + 1]))
+        for i, j in pairs:
+            ops.append(_g("cx", [i, j]))
+            ops.append(_g("p", [j], (lambda P, i=i, j=j: 2 * (PI - P[:, i]) * (PI - P[:, j])), [i, j]))
+            ops.append(_g("cx", [i, j]))
     return ops
 
 

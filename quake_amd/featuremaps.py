@@ -33,8 +33,16 @@ def z_featuremap(x: ParameterVector, qubits: int, repeats: int = 1, align: bool 
     return circ
 
 
-def zz_featuremap(x: ParameterVector, qubits: int, repeats: int = 1, align: bool = False) -> QuantumCircuit:
-    """The ZZ feature map, linear entanglement (reference quantum_featuremaps.py:44-81)."""
+def zz_featuremap(x: ParameterVector, qubits: int, repeats: int = 1, align: bool = False,
+                  entanglement: str = "linear") -> QuantumCircuit:
+    """The ZZ feature map (reference quantum_featuremaps.py:44-81).  The reference builds LINEAR
+    entanglement (neighbouring qubits); ``entanglement="full"`` is the Qiskit library default
+    (every pair i < j, in ``itertools.combinations`` order), offered because SURVEY 8d asks for it
+    as a separately reported variant -- no reference run uses it."""
+    if entanglement not in ("linear", "full"):
+        raise ValueError(f"entanglement must be 'linear' or 'full', got {entanglement!r}")
+    pairs = [(q, q + 1) for q in range(qubits - 1)] if entanglement == "linear" else \
+        [(i, j) for i in range(qubits) for j in range(i + 1, qubits)]
     circ = QuantumCircuit(qubits)
     if align:
         _align_prefix(circ, qubits)
@@ -42,10 +50,10 @@ def zz_featuremap(x: ParameterVector, qubits: int, repeats: int = 1, align: bool
         for q in range(qubits):
             circ.h(q)
             circ.p(2 * x[q], q)
-        for q in range(qubits - 1):
-            circ.cx(q, q + 1)
-            circ.p(2 * (np.pi - x[q]) * (np.pi - x[q + 1]), q + 1)
-            circ.cx(q, q + 1)
+        for i, j in pairs:
+            circ.cx(i, j)
+            circ.p(2 * (np.pi - x[i]) * (np.pi - x[j]), j)
+            circ.cx(i, j)
         circ.barrier()
     return circ
 
@@ -187,13 +195,14 @@ _TWO_QUBIT_ONLY = {
 }
 
 
-def build_featuremap(name: str, qubits: int, repeats: int = 1, align: bool = False) -> QuantumCircuit:
+def build_featuremap(name: str, qubits: int, repeats: int = 1, align: bool = False, **options) -> QuantumCircuit:
     """Runcard entry point: build a named map over ``x = ParameterVector("x", qubits)``
-    (what ``load_quantum_kernels`` does at reference qsvm/train.py:180-184)."""
+    (what ``load_quantum_kernels`` does at reference qsvm/train.py:180-184).  ``options`` go to the
+    builder (``entanglement: full`` for the ZZ map)."""
     key = name.lower()
     if key not in FEATURE_MAPS:
         raise KeyError(f"unknown feature map '{name}'; known: {sorted(FEATURE_MAPS)}")
     x = ParameterVector("x", length=max(int(qubits), 2 if key in _TWO_QUBIT_ONLY else 1))
     if key in _TWO_QUBIT_ONLY:
-        return FEATURE_MAPS[key](x, repeats=repeats, align=align)
-    return FEATURE_MAPS[key](x, qubits, repeats=repeats, align=align)
+        return FEATURE_MAPS[key](x, repeats=repeats, align=align, **options)
+    return FEATURE_MAPS[key](x, qubits, repeats=repeats, align=align, **options)

@@ -62,6 +62,7 @@ def map_pairs(n, repeats):
     pairs = {
         "z": (fm.z_featuremap(x, n, repeats), O.z_featuremap(n, repeats), n),
         "zz": (fm.zz_featuremap(x, n, repeats), O.zz_featuremap(n, repeats), n),
+        "zz_full": (fm.zz_featuremap(x, n, repeats, entanglement="full"), O.zz_featuremap(n, repeats, "full"), n),
         "custom1": (fm.custom1_featuremap(x, n, repeats), O.custom1_featuremap(n, repeats), n),
         "custom2": (fm.custom2_featuremap(x, n, repeats), O.custom2_featuremap(n, repeats), n),
     }

@@ -42,6 +42,7 @@ def test_statevectors_two_qubit_maps(repeats):
 
 @pytest.mark.parametrize("n,builder,repeats,N", [
     (12, "zz", 1, 5), (13, "custom1", 1, 3), (14, "zz", 2, 3), (15, "custom1", 1, 2), (16, "zz", 1, 2), (16, "custom1", 2, 2),
+    (13, "zz_full", 1, 3), (15, "zz_full", 2, 2),
 ])
 def test_statevectors_large_and_multipass(n, builder, repeats, N):
     """n > 13 does not fit one workgroup's LDS: the simulator runs several HBM passes."""

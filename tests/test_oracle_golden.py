@@ -93,6 +93,23 @@ def test_zz_closed_form():
     assert np.abs(psi - np.exp(1j * phi) / 2 ** (n / 2)).max() < 1e-13
 
 
+def test_zz_full_entanglement_closed_form():
+    """entanglement="full" (Qiskit library default, not built by the reference): every pair i < j."""
+    n, N = 5, 6
+    X = np.random.default_rng(8).uniform(-1.5, 1.5, size=(N, n))
+    psi = O.statevectors(O.zz_featuremap(n, 1, "full"), n, X)
+    b = (np.arange(1 << n)[:, None] >> np.arange(n)) & 1
+    phi = 2 * (X @ b.T)
+    for i in range(n):
+        for j in range(i + 1, n):
+            phi = phi + np.outer(2 * (np.pi - X[:, i]) * (np.pi - X[:, j]), b[:, i] ^ b[:, j])
+    assert np.abs(psi - np.exp(1j * phi) / 2 ** (n / 2)).max() < 1e-13
+    with pytest.raises(ValueError):
+        from quake_amd import featuremaps as fm
+        from quake_amd.circuit import ParameterVector
+        fm.zz_featuremap(ParameterVector("x", 3), 3, 1, entanglement="circular")
+
+
 def test_unitarity_and_psd():
     n, N = 5, 40
     X = np.random.default_rng(6).uniform(-1.5, 1.5, size=(N, n))
