@@ -69,6 +69,16 @@ int qk_device_count(void);
 int qk_last_error(char* buf, size_t len);
 
 /*
+ * Page-locked host memory for the buffers the host entry points fill (K, Psi).  The reference hands
+ * back a fresh numpy array per evaluate() call ("fresh array owned by the caller");
+ * an array that lives in memory from qk_host_alloc receives K at the PCIe rate (measured 53 GiB/s
+ * against 9 GiB/s into fresh pageable pages).  Optional: every host entry point accepts any host
+ * pointer.  The caller releases the memory with qk_host_free.
+ */
+int qk_host_alloc(size_t bytes, void** out);
+int qk_host_free(void* p);
+
+/*
  * Replaces: building a qiskit QuantumCircuit over a ParameterVector
  * (reference quantum_featuremaps.py:9-387, genetic_v3.py:363-448) plus
  * QuantumCircuit.assign_parameters: angle program e reads data

@@ -52,6 +52,8 @@ SIGNATURES = {
     "qk_version": (C.c_int, []),
     "qk_device_count": (C.c_int, []),
     "qk_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "qk_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "qk_host_free": (C.c_int, [C.c_void_p]),
     "qk_circuit_create": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
                                     C.POINTER(_P)]),
     "qk_circuit_destroy": (None, [_P]),
@@ -130,6 +132,39 @@ def last_error() -> str:
 def check(rc: int) -> None:
     if rc != QK_OK:
         raise QkError(rc, last_error())
+
+
+PINNED_MIN_BYTES = 1 << 20   # below this a pageable numpy array costs nothing measurable
+
+
+class _PinnedBlock:
+    """Page-locked host memory from qk_host_alloc, released when the last numpy view of it dies."""
+
+    def __init__(self, nbytes: int, shape, dtype):
+        out = C.c_void_p()
+        check(load().qk_host_alloc(nbytes, C.byref(out)))
+        self._ptr = out.value
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": np.dtype(dtype).str,
+                                    "data": (self._ptr, False), "version": 3}
+
+    def __del__(self):
+        p, self._ptr = getattr(self, "_ptr", None), None
+        if p and _lib is not None:
+            _lib.qk_host_free(p)
+
+
+def host_empty(shape, dtype=np.float64) -> np.ndarray:
+    """``np.empty`` for an output the library fills: page-locked (qk_host_alloc) when it is large, so the
+    device-to-host copy runs at the PCIe rate; an ordinary array when it is small or pinning fails.
+    Either way a fresh, writable, C-contiguous array the caller owns."""
+    shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    if nbytes >= PINNED_MIN_BYTES:
+        try:
+            return np.asarray(_PinnedBlock(nbytes, shape, dtype))
+        except QkError:
+            pass    # e.g. the locked-memory limit: the pageable path below is only slower
+    return np.empty(shape, dtype=dtype)
 
 
 def ptr(a: np.ndarray):

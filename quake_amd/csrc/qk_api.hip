@@ -126,6 +126,23 @@ extern "C" int qk_circuit_num_qubits(const qk_circuit* c) { return c ? c->n_qubi
 extern "C" int qk_circuit_num_params(const qk_circuit* c) { return c ? c->n_params : QK_ERR_INVALID; }
 extern "C" int qk_circuit_num_passes(const qk_circuit* c) { return c ? (int)c->passes.size() : QK_ERR_INVALID; }
 
+extern "C" int qk_host_alloc(size_t bytes, void** out) {
+    using namespace qk;
+    if (!out) return fail(QK_ERR_INVALID, "qk_host_alloc: out is null");
+    *out = nullptr;
+    int rc = check_device();
+    if (rc) return rc;
+    QK_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return QK_OK;
+}
+
+extern "C" int qk_host_free(void* p) {
+    using namespace qk;
+    if (!p) return QK_OK;
+    QK_HIP(hipHostFree(p));
+    return QK_OK;
+}
+
 extern "C" int qk_simulate(const qk_circuit* c, const double* X, int64_t N, int64_t ldx, void* psi_host) {
     if (!c || !psi_host) return fail(QK_ERR_INVALID, "qk_simulate: null pointer");
     if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate: negative N");

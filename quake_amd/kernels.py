@@ -161,7 +161,7 @@ class HipFidelityKernel:
         lib = _lib.load()
         circ = self._circuit()
         n, m = x.shape[0], (x.shape[0] if y is None else y.shape[0])
-        K = np.empty((n, m), dtype=np.float64)
+        K = _lib.host_empty((n, m))
         _lib.check((lib.qk_evaluate if self._precision == "double" else lib.qk_evaluate_f32)(
             circ.handle, _lib.ptr(x), n,
             _lib.ptr(y) if y is not None else None, m, x.shape[1], _lib.ptr(K)))
@@ -174,7 +174,7 @@ class HipFidelityKernel:
         x, _ = self._validate(x_vec, None)
         lib = _lib.load()
         circ = self._circuit()
-        psi = np.empty((x.shape[0], 1 << circ.n_qubits), dtype=np.complex128)
+        psi = _lib.host_empty((x.shape[0], 1 << circ.n_qubits), np.complex128)
         _lib.check(lib.qk_simulate(circ.handle, _lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(psi)))
         return psi
 
@@ -220,7 +220,7 @@ def projected_quantum_kernel(fmap: QuantumCircuit, dataset: np.ndarray, gamma: f
             f"feature map has {compiled.n_params} parameters.")
     lib = _lib.load()
     circ = _lib.CircuitHandle(compiled)
-    K = np.empty((N, N), dtype=np.float64)
+    K = _lib.host_empty((N, N))
     _lib.check(lib.qk_projected_kernel(circ.handle, _lib.ptr(X), N, X.shape[1], float(gamma), _lib.ptr(K)))
     return K
 
@@ -282,7 +282,7 @@ def evaluate_population(feature_maps: Sequence[QuantumCircuit], x_vecs: Sequence
     x_arr = (P * count)(*[x.ctypes.data if x.size else None for x in xs])
     n_arr = (C.c_int64 * count)(*[x.shape[0] for x in xs])
     lab_arr = (P * count)(*[l.ctypes.data for l in lab]) if lab is not None else None
-    Ks = [np.empty((x.shape[0], x.shape[0]), dtype=np.float64) for x in xs] if return_kernels else None
+    Ks = [_lib.host_empty((x.shape[0], x.shape[0])) for x in xs] if return_kernels else None
     k_arr = (P * count)(*[k.ctypes.data for k in Ks]) if Ks is not None else None
     sums = np.zeros((count, _lib.STATS_LEN), dtype=np.float64) if lab is not None else None
     if Ks is None and sums is None:

@@ -282,6 +282,37 @@ def test_gram_raw_layout_asymmetric():
         assert (S[0] == -1).all() and (S[:, :2] == -1).all() and (S[N + 1:] == -1).all() and (S[:, N + 2:] == -1).all()
 
 
+def test_pinned_output_arrays():
+    """Large outputs of the host entry points live in page-locked memory (qk_host_alloc) so that K comes
+    back at the PCIe rate; to the caller they are ordinary fresh numpy arrays."""
+    import ctypes as C
+    import gc
+    from quake_amd import _lib
+    lib = _lib.load()
+    p = C.c_void_p()
+    assert lib.qk_host_alloc(1 << 16, C.byref(p)) == 0 and p.value
+    C.memset(p.value, 0xAB, 1 << 16)
+    assert lib.qk_host_free(p) == 0 and lib.qk_host_free(None) == 0
+    assert lib.qk_host_alloc(16, None) != 0
+    n, N = 4, 600                                   # 600 x 600 doubles > PINNED_MIN_BYTES
+    circ, oops, _ = map_pairs(n, 1)["custom1"]
+    X = synth_X(N, n, "scaled", 3)
+    K = HipFidelityKernel(circ).evaluate(X)
+    assert K.nbytes >= _lib.PINNED_MIN_BYTES and isinstance(K.base, _lib._PinnedBlock)
+    assert K.flags.writeable and K.flags.c_contiguous and K.dtype == np.float64
+    assert np.abs(K - O.evaluate(oops, n, X)).max() < TOL_K
+    view = K[10:20]
+    del K
+    gc.collect()
+    assert view[0, 10] == 1.0                       # a view keeps the block alive
+    K2 = np.array(view)                              # ordinary copy semantics
+    del view
+    gc.collect()
+    assert K2[0, 10] == 1.0
+    small = HipFidelityKernel(circ).evaluate(X[:8])
+    assert small.base is None                        # small outputs stay pageable
+
+
 def test_projected_kernel_distance_scales():
     """The pairwise kernel's square root is hand-rolled (hardware rsq seed + refinement): rows that
     differ by 1 down to 1e-12 per component, against a long-double evaluation of the same formula
