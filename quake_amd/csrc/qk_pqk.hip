@@ -71,19 +71,42 @@ __global__ void __launch_bounds__(RDM_THREADS) rdm1_lds_kernel(const double2* __
 
 constexpr int PT = 64;  // pqk tile side: 256 threads x (4 x 4) entries
 
-// sqrt for x in [0, 16]: the pairwise kernel is bound by one square root per (pair, qubit), and the
-// library routine spends half its instructions on range scaling this input never needs.  Hardware
-// reciprocal-square-root seed (~26 bits), one Goldschmidt step and a residual correction: the kernel
-// matrix stays within 1 ulp of a long-double evaluation for distances from 1 down to 1e-12.
-__device__ __forceinline__ double sqrt_small(double x) {
-    const double y = __builtin_amdgcn_rsq(x);        // +inf for x == 0, handled by the select below
-    double g = x * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double d = fma(-g, g, x);                  // residual correction: g += (x - g^2) * h
-    g = fma(d, h, g);
-    return x < 1e-280 ? 0.0 : g;
+// The pairwise kernel is bound by VALU issue (PMC: 88 % busy), most of it the square root per (pair,
+// qubit); the library routine spends half its instructions on range scaling this input (x in [0, 16])
+// never needs.  Here: hardware reciprocal-square-root seed y (~26 bits), g = x * y, and one residual
+// correction, sqrt(x) = g + (x - g^2) * y / 2 (relative error ~2^-52).  The loop accumulates TWICE the
+// root, 2 g + (x - g^2) y, as two fused multiply-adds; the factor 1/2 goes into the exponent.  x carries
+// an addend of 1e-300 so that rsq never sees 0 (identical rows: sqrt = 1e-150 instead of 0, far below
+// one ulp of the exponent's argument).
+__device__ __forceinline__ double add_twice_sqrt(double acc, double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y;
+    const double d = fma(-g, g, x);
+    return fma(2.0, g, fma(d, y, acc));
+}
+
+// exp(x) for the epilogue, one fused multiply-add per polynomial step: the coefficients are read from
+// a mutable global (so they are not folded into the instruction stream) with scalar loads and sit
+// in SGPRs as the addend of v_fma_f64 -- the library routine's constants have to be moved into the
+// destination register pair of a v_fmac_f64 before every step (3 VALU instructions per step, and
+// the epilogue was a quarter of the kernel's VALU time at 12 qubits).
+// k = rint(x / ln 2), r = x - k ln 2 in two pieces (|r| <= 0.347), Taylor polynomial of degree 13
+// (remainder < 4e-18), result scaled by 2^k; underflows to 0 like the library routine.
+__device__ double g_exp_coef[12] = {
+    1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+    1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0,      0.5};
+
+__device__ __forceinline__ double exp_poly(double x, const double (&c)[12]) {
+    x = fmax(x, -800.0);
+    const double k = rint(x * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = c[0];
+#pragma unroll
+    for (int t = 1; t < 12; ++t) p = fma(p, r, c[t]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
 }
 
 // LDS image per side: [qubit][component][row] (rows contiguous): the 16 lanes that differ in their
@@ -111,8 +134,11 @@ __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx,
     for (int e = tid; e < PT * w; e += 256) {
         const int r = e / w, c = e % w;   // global reads: consecutive lanes walk one RDM row
         const int64_t gi = (int64_t)ti * PT + r, gj = (int64_t)tj * PT + r;
-        sx[c * PT + r] = gi < N ? rx[gi * w + c] : 0.0;
-        sy[c * PT + r] = gj < M ? ry[gj * w + c] : 0.0;
+        // components 2, 3 (Re, Im of rho01) are stored times sqrt(2): |d00|^2 + |d11|^2 + 2 |d01|^2
+        // becomes a plain sum of four squares
+        const double sc = (c & 2) ? 1.4142135623730951 : 1.0;
+        sx[c * PT + r] = gi < N ? sc * rx[gi * w + c] : 0.0;
+        sy[c * PT + r] = gj < M ? sc * ry[gj * w + c] : 0.0;
     }
     __syncthreads();
     const int tx = tid & 15, ty = tid >> 4;
@@ -137,26 +163,43 @@ __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx,
                 const double d0 = a[r][0] - b[c][0], d1 = a[r][1] - b[c][1];
                 const double dr = a[r][2] - b[c][2], di = a[r][3] - b[c][3];
                 // Frobenius norm of the 2x2 difference: |d00|^2 + |d11|^2 + 2 |d01|^2
-                acc[r][c] += sqrt_small(fma(d0, d0, fma(d1, d1, 2.0 * fma(dr, dr, di * di))));
+                acc[r][c] = add_twice_sqrt(acc[r][c], fma(d0, d0, fma(d1, d1, fma(dr, dr, fma(di, di, 1e-300)))));
             }
     }
-    const bool diag_tile = sym && ti == tj;
+    // exponentials first, branch-free over the whole 4 x 4 block (so the polynomial's constants are
+    // loaded once), then the predicated stores
+    double ec[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) ec[t] = g_exp_coef[t];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = exp_poly(-0.5 * gamma * acc[r][c], ec);   // acc = 2 * sum_q ||rho_i^q - rho_j^q||_F
+    const bool diag_tile = sym && ti == tj;
+    const int64_t i0 = (int64_t)ti * PT + ty, j0 = (int64_t)tj * PT + tx;
+    double* KjT[4];   // mirror entries: row j of K, offset to column i0
+#pragma unroll
+    for (int c = 0; c < 4; ++c) KjT[c] = K + (j0 + 16 * c) * ldk + i0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + 16 * r;
+        if (i >= N) continue;
+        double* Ki = K + i * ldk;
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int64_t i = (int64_t)ti * PT + ty + 16 * r, j = (int64_t)tj * PT + tx + 16 * c;
-            if (i >= N || j >= M) continue;
-            double v = exp(-gamma * acc[r][c]);
+            const int64_t j = j0 + 16 * c;
+            if (j >= M) continue;
+            double v = acc[r][c];
             if (sym) {
                 if (i == j) v = 1.0;            // reference adds the identity (genetic_v3.py:805)
                 else if (diag_tile && i > j) continue;
-                K[i * ldk + j] = v;
-                if (i != j) K[j * ldk + i] = v;
+                Ki[j] = v;
+                if (i != j) KjT[c][16 * r] = v;
             } else {
-                K[i * ldk + j] = v;
+                Ki[j] = v;
             }
         }
+    }
 }
 
 }  // namespace qk

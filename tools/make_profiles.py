@@ -78,6 +78,37 @@ are bound by FP64 VALU issue (angle programs, phase tables, butterflies), not by
 conflicts are a few percent of LDS-active cycles in every pass (the butterflies on the lowest qubits use an
 XOR-swizzled register mapping).
 """
+
+def pqk_counters(p):
+    c = sqlite3.connect(O + p + "/p_results.db").cursor()
+    rows = {}
+    for name, cn, did, val, dur in c.execute("select kernel_name, counter_name, dispatch_id, value, duration from counters_collection order by dispatch_id"):
+        if "pqk_kernel" in name: rows.setdefault(did, {"dur_ns": dur})[cn] = val
+    return rows[sorted(rows)[-1]]
+try:
+    G, H = pqk_counters("pmcG"), pqk_counters("pmcH")
+except Exception:
+    G = H = None
+if G:
+    Np, nq = 32768, 12
+    roots = Np * (Np + 1) // 2 * nq
+    cyc = G["GRBM_GUI_ACTIVE"] / 8
+    f64 = G["SQ_INSTS_VALU_FMA_F64"] + G["SQ_INSTS_VALU_ADD_F64"] + G["SQ_INSTS_VALU_MUL_F64"]
+    busy = G["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * 1024)
+    md += f"""
+## qk::pqk_kernel: `tools/config_bench.py 4` (projected kernel, N=32768, 12 qubits, symmetric; last launch)
+
+| quantity | value |
+|---|---|
+| duration | {G['dur_ns']/1e6:.2f} ms at {cyc/G['dur_ns']:.2f} GHz (GRBM_GUI_ACTIVE / 8) |
+| WRITE_SIZE | {H['WRITE_SIZE']:.6g} KiB = {H['WRITE_SIZE']*1024:.4g} B (K is N*N*8 = {Np*Np*8:.4g} B, the algorithmic bytes) -> {H['WRITE_SIZE']*1024/H['dur_ns']:.0f} GB/s: far under the HBM roof |
+| SQ_INSTS_VALU_TRANS_F64 | {G['SQ_INSTS_VALU_TRANS_F64']:.6g} wave instructions = N(N+1)/2 * n / 64 = {roots/64:.6g}: one v_rsq_f64 per (pair, qubit) |
+| SQ_INSTS_VALU_{{FMA,ADD,MUL}}_F64 | {G['SQ_INSTS_VALU_FMA_F64']:.4g} + {G['SQ_INSTS_VALU_ADD_F64']:.4g} + {G['SQ_INSTS_VALU_MUL_F64']:.4g} = {f64/G['SQ_INSTS_VALU_TRANS_F64']:.1f} FP64 operations per root (4 differences, 4 squares, 4 for the root and its accumulation; the rest is the exp epilogue) |
+| SQ_INSTS_VALU | {G['SQ_INSTS_VALU']:.6g} ({G['SQ_INSTS_VALU']/G['SQ_INSTS_VALU_TRANS_F64']:.1f} per root) |
+| SQ_ACTIVE_INST_VALU | {G['SQ_ACTIVE_INST_VALU']:.6g} (units of 4 cycles) / (cycles x 1024 SIMDs) = **{busy*100:.0f}% VALU busy** |
+
+Reading: the pairwise kernel is bound by FP64 VALU issue, not by the 8 bytes per entry it writes.
+"""
 open("profiles/r01_pmc.md", "w").write(md)
 json.dump({"workload": {"rows": 65536, "qubits": 16, "repeats": 1, "gpus": 1},
            "gram_hbm_bytes_per_launch": fetch + write, "gram_fetch_bytes": fetch, "gram_write_bytes": write,
