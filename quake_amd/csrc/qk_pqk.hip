@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(RDM_THREADS) rdm1_lds_kernel(const double2* __
     }
 }
 
-constexpr int PT = 64;  // pqk tile side: 256 threads x (4 x 4) entries
+constexpr int PT = 64;   // pqk tile side: 256 threads x (4 x 4) entries
+constexpr int PTP = 65;  // row stride of the LDS image: the staging writes walk components, 65 keeps them on distinct banks
 
 // The pairwise kernel is bound by VALU issue (PMC: 88 % busy), most of it the square root per (pair,
 // qubit); the library routine spends half its instructions on range scaling this input (x in [0, 16])
@@ -116,29 +117,45 @@ __device__ __forceinline__ double exp_poly(double x, const double (&c)[12]) {
 __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx, int64_t N,
                                                    const double* __restrict__ ry, int64_t M, int n, double gamma,
                                                    double* __restrict__ K, int64_t ldk, int sym, int tiles_n) {
-    extern __shared__ double sh[];  // x side then y side, each [n][4][PT]
+    extern __shared__ double sh[];  // x side then y side, each [n][4][PTP]
     int ti, tj;
-    if (sym) {  // upper-triangular tile list: blockIdx -> (ti, tj >= ti)
-        int rem = blockIdx.x, row = 0, len = tiles_n;
-        while (rem >= len) { rem -= len; --len; ++row; }
+    if (sym) {  // upper-triangular tile list: blockIdx -> (ti, tj >= ti); T(r) = r * tiles_n - r (r - 1) / 2 tiles precede row r
+        const int b = blockIdx.x;
+        const double t2 = 2.0 * tiles_n + 1.0;
+        int row = (int)(0.5 * (t2 - sqrt(fmax(t2 * t2 - 8.0 * b, 0.0))));
+        row = row < 0 ? 0 : (row >= tiles_n ? tiles_n - 1 : row);
+        auto before = [&](int r) { return (int64_t)r * tiles_n - (int64_t)r * (r - 1) / 2; };
+        while (row > 0 && before(row) > b) --row;                 // guards the rounding of the estimate
+        while (row + 1 < tiles_n && before(row + 1) <= b) ++row;
         ti = row;
-        tj = row + rem;
+        tj = row + (int)(b - before(row));
     } else {
         ti = blockIdx.x / tiles_n;
         tj = blockIdx.x % tiles_n;
     }
     const int w = n * 4;
     double* sx = sh;
-    double* sy = sh + PT * w;
+    double* sy = sh + PTP * w;
     const int tid = threadIdx.x;
-    for (int e = tid; e < PT * w; e += 256) {
-        const int r = e / w, c = e % w;   // global reads: consecutive lanes walk one RDM row
-        const int64_t gi = (int64_t)ti * PT + r, gj = (int64_t)tj * PT + r;
-        // components 2, 3 (Re, Im of rho01) are stored times sqrt(2): |d00|^2 + |d11|^2 + 2 |d01|^2
-        // becomes a plain sum of four squares
-        const double sc = (c & 2) ? 1.4142135623730951 : 1.0;
-        sx[c * PT + r] = gi < N ? sc * rx[gi * w + c] : 0.0;
-        sy[c * PT + r] = gj < M ? sc * ry[gj * w + c] : 0.0;
+    {
+        // The tile's 64 RDM rows are one contiguous run of 64 * w doubles: read it linearly (coalesced)
+        // and keep (row, component) of the element by increments instead of a division per element.
+        const int total = PT * w;
+        const int64_t xbase = (int64_t)ti * total, ybase = (int64_t)tj * total;
+        const int xl = (int)(N * w - xbase < total ? N * w - xbase : total);   // elements of existing rows
+        const int yl = (int)(M * w - ybase < total ? M * w - ybase : total);
+        int r = tid / w, c = tid - r * w;
+        const int dr = 256 / w, dc = 256 - dr * w;
+        for (int e = tid; e < total; e += 256) {
+            // components 2, 3 (Re, Im of rho01) are stored times sqrt(2): |d00|^2 + |d11|^2 + 2 |d01|^2
+            // becomes a plain sum of four squares
+            const double sc = (c & 2) ? 1.4142135623730951 : 1.0;
+            sx[c * PTP + r] = e < xl ? sc * rx[xbase + e] : 0.0;
+            sy[c * PTP + r] = e < yl ? sc * ry[ybase + e] : 0.0;
+            r += dr;
+            c += dc;
+            if (c >= w) { c -= w; ++r; }
+        }
     }
     __syncthreads();
     const int tx = tid & 15, ty = tid >> 4;
@@ -153,8 +170,8 @@ __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx,
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                a[r][k] = sx[(q * 4 + k) * PT + ty + 16 * r];
-                b[r][k] = sy[(q * 4 + k) * PT + tx + 16 * r];
+                a[r][k] = sx[(q * 4 + k) * PTP + ty + 16 * r];
+                b[r][k] = sy[(q * 4 + k) * PTP + tx + 16 * r];
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -176,27 +193,28 @@ __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx,
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = exp_poly(-0.5 * gamma * acc[r][c], ec);   // acc = 2 * sum_q ||rho_i^q - rho_j^q||_F
     const bool diag_tile = sym && ti == tj;
-    const int64_t i0 = (int64_t)ti * PT + ty, j0 = (int64_t)tj * PT + tx;
+    const int i0 = ti * PT + ty, j0 = tj * PT + tx;    // N, M < 2^31 (checked by the host)
+    const int Ni = (int)N, Mi = (int)M;
     double* KjT[4];   // mirror entries: row j of K, offset to column i0
 #pragma unroll
-    for (int c = 0; c < 4; ++c) KjT[c] = K + (j0 + 16 * c) * ldk + i0;
+    for (int c = 0; c < 4; ++c) KjT[c] = K + (int64_t)(j0 + 16 * c) * ldk + i0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int64_t i = i0 + 16 * r;
-        if (i >= N) continue;
-        double* Ki = K + i * ldk;
+        const int i = i0 + 16 * r;
+        if (i >= Ni) continue;
+        double* Ki = K + (int64_t)i * ldk + j0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int64_t j = j0 + 16 * c;
-            if (j >= M) continue;
+            const int j = j0 + 16 * c;
+            if (j >= Mi) continue;
             double v = acc[r][c];
             if (sym) {
                 if (i == j) v = 1.0;            // reference adds the identity (genetic_v3.py:805)
                 else if (diag_tile && i > j) continue;
-                Ki[j] = v;
+                Ki[16 * c] = v;
                 if (i != j) KjT[c][16 * r] = v;
             } else {
-                Ki[j] = v;
+                Ki[16 * c] = v;
             }
         }
     }
@@ -237,11 +255,12 @@ extern "C" int qk_pqk_dev(const double* rdm_x, int64_t N, const double* rdm_y, i
     const int sym = rdm_y ? 0 : 1;
     if (sym) { rdm_y = rdm_x; M = N; }
     if (N < 0 || M < 0 || ldk < M) return fail(QK_ERR_INVALID, "qk_pqk_dev: bad shape");
+    if (N > 0x7fffffffLL - PT || M > 0x7fffffffLL - PT) return fail(QK_ERR_UNSUPPORTED, "qk_pqk_dev: more than 2^31 rows");
     if (N == 0 || M == 0) return QK_OK;
     const int64_t tm = (N + PT - 1) / PT, tn = (M + PT - 1) / PT;
     const int64_t nblocks = sym ? tn * (tn + 1) / 2 : tm * tn;
     if (nblocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, "qk_pqk_dev: too many tiles");
-    const size_t lds = (size_t)2 * PT * n_qubits * 4 * sizeof(double);
+    const size_t lds = (size_t)2 * PTP * n_qubits * 4 * sizeof(double);
     if (lds > 64 * 1024) {
         static DeviceOnce attr_set;
         if (attr_set.pending()) {
