@@ -200,7 +200,7 @@ def pqk_main(a, rank, world, dev, dist):
             "roofline": {"bound": "hbm", "achieved": written / (pair_ms * 1e-3) / 1e9 if pair_ms else 0.0, "peak": 8000.0,
                          "unit": "GB/s", "frac": written / (pair_ms * 1e-3) / 1e9 / 8000.0 if pair_ms else 0.0, "traffic": None,
                          "kernel": "qk::pqk_kernel", "note": "8 bytes written per entry of rank 0's block / pairwise-kernel time "
-                         "(includes the RDM all-gather at N>1); the kernel is bound by one FP64 rsqrt per (pair, qubit)"},
+                         "(includes the RDM all-gather at N>1); the kernel is bound by FP64 VALU issue (12 operations + one rsq per (pair, qubit); PMC: 80 % VALU busy), not by these bytes"},
             "stages_ms": {"simulate_rdm1": sim_ms, "pairwise": pair_ms}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
