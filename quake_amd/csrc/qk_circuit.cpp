@@ -266,9 +266,18 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 auto row_bit = [&](const DevTerm& t) { return (t.va >= ps.h ? t.va : t.vb) - ps.h; };
                 std::stable_sort(cross.begin(), cross.end(),
                                  [&](const auto& x, const auto& y) { return row_bit(x.first) < row_bit(y.first); });
+                auto chunk_dep = [&](const std::pair<DevTerm, int>& te) {
+                    const DevTerm& t = te.first;
+                    const bool two = t.type == TM_CZ || t.type == TM_ZZP;
+                    return t.va >= ps.L || (two && t.vb >= ps.L);
+                };
+                std::stable_partition(lo.begin(), lo.end(), [&](const auto& te) { return !chunk_dep(te); });
+                std::stable_partition(hi.begin(), hi.end(), [&](const auto& te) { return !chunk_dep(te); });
                 st.nLo = (int)lo.size();
                 st.nHi = (int)hi.size();
                 st.nX = (int)cross.size();
+                st.nLoD = (int)std::count_if(lo.begin(), lo.end(), chunk_dep);
+                st.nHiD = (int)std::count_if(hi.begin(), hi.end(), chunk_dep);
                 for (int a = 0, k = 0; a <= kMaxRowBits; ++a) {
                     while (k < st.nX && row_bit(cross[k].first) < a) ++k;
                     st.xo[a] = k;

@@ -63,6 +63,9 @@ struct DevStage {
     // by their row bit: the terms with row bit h+a are [xo[a], xo[a+1]) of the nX
     int32_t t0, nLo, nHi, nX;
     int32_t xo[kMaxRowBits + 1];
+    // the last nLoD of the nLo and the last nHiD of the nHi involve a chunk bit (>= L): only those have
+    // to be re-evaluated from one chunk of a sample to the next
+    int32_t nLoD, nHiD;
     // INIT: the first gate on a still-|0> qubit (virtual bit va, local or chunk):
     //       amplitude *= entry [bit va][0] of matrix gm[0]
 };

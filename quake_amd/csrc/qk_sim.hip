@@ -39,6 +39,7 @@ struct SimArgs {
     int L, h, lgT, n_qubits, first;
     uint32_t zero_in, zero_out;  // virtual-bit masks of still-|0> qubits (see Pass)
     int n_init;                  // first pass: leading ST_INIT stages (hoisted first gates)
+    int hoist;                   // per-sample base tables for the fused first diagonal stage (several chunks per sample)
     uint32_t live_chunks;        // chunk-index bits that are not known-zero after the pass
     int nlive;                   // popcount(live_chunks)
     int64_t n_items;             // N << nlive (sample, live chunk) pairs
@@ -242,7 +243,9 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     double2* tlo = mat + 4 * a.n_mat;                       // phase table over local bits < h
     double2* thi = tlo + (1u << h);                         // phase table over local bits >= h
     double2* rat = thi + (1u << (L - h));                   // [row bit][column]: cross-term ratio of setting that bit
-    double* xbuf = (double*)(rat + ((uint32_t)(L - h) << h));   // feature rows of this item and the next
+    double2* blo = rat + ((uint32_t)(L - h) << h);          // chunk-independent part of tlo / thi (hoist mode only)
+    double2* bhi = blo + (1u << h);
+    double* xbuf = a.hoist ? (double*)(bhi + (1u << (L - h))) : (double*)blo;   // feature rows of this item and the next
     const int xs = (a.n_params + 1) & ~1;
     DevExpr* s_expr = (DevExpr*)(xbuf + 2 * xs);            // staged angle programs (a.staged)
     qk_instr* s_prog = (qk_instr*)(s_expr + a.n_expr);
@@ -298,6 +301,10 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     // A diagonal stage right after the hoisted first gates (every Z / ZZ map) takes the product
     // state as two more factors of its tables: the state is written once, phases included.
     const bool fuse_init = a.first && a.n_init > 0 && a.n_init < a.n_stage && a.stages[a.n_init].kind == ST_DIAG;
+    // Several chunks per sample: what those tables owe to local bits only (the product state's factors,
+    // the terms without a chunk bit, the cross-term ratios) is computed once per sample; a chunk
+    // multiplies in its scalar and the few terms that read a chunk bit.
+    const bool hoist = a.hoist != 0;    // = fuse_init && a.nlive > 0, decided by the host with the LDS layout
     int par = 0;
     int64_t angles_of = -1;     // the sample whose (cos, sin) values sit in rt / mat
     for (int64_t item = item_begin; item < item_end; ++item) {
@@ -333,13 +340,79 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             if (a.staged) run_angle_programs(s_expr, s_prog, s_const, xrow, a.n_expr, rt, mat, tid, T);
             else run_angle_programs(a.exprs, a.prog, a.consts, xrow, a.n_expr, rt, mat, tid, T);
             angles_of = sample;
+            if (hoist) {
+                __syncthreads();
+                const DevStage st = a.stages[a.n_init];
+                const RTerm* tl = rt + st.t0;
+                const RTerm* th = tl + st.nLo;
+                const RTerm* tx = th + st.nHi;
+                const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
+                const uint32_t n_rat = st.nX ? (nlo * (uint32_t)(L - h)) : 0u;
+                for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
+                    double fr = 1.0, fi = 0.0;
+                    if (j < n_rat) {
+                        const uint32_t c = j & (nlo - 1u);
+                        const uint32_t ra = __builtin_amdgcn_readfirstlane(j >> h);
+                        const uint32_t w1 = c | (1u << (h + ra));
+                        const int32_t* xo = a.stages[a.n_init].xo;
+                        double gr = 1.0, gi = 0.0;
+                        for (int k = xo[ra]; k < xo[ra + 1]; ++k) {
+                            apply_term(tx[k], w1, fr, fi);
+                            apply_term(tx[k], c, gr, gi);
+                        }
+                        rat[j] = make_double2(fma(fr, gr, fi * gi), fma(fi, gr, -(fr * gi)));
+                    } else {
+                        const bool is_lo = j < n_rat + nlo;
+                        const uint32_t e = j - n_rat - (is_lo ? 0u : nlo);
+                        const uint32_t w = is_lo ? e : (e << h);
+                        if (w & a.zero_in) fr = 0.0;
+                        double2 f = make_double2(fr, 0.0);
+                        for (int q = 0; q < a.n_init; ++q) {
+                            const int2 g = s_init[q];
+                            if (g.x < L && (g.x < h) == is_lo) f = cmul(f, mat[4 * g.y + 2 * ((w >> g.x) & 1u)]);
+                        }
+                        fr = f.x; fi = f.y;
+                        if (is_lo) {
+                            for (int k = 0; k < st.nLo - st.nLoD; ++k) apply_term(tl[k], w, fr, fi);
+                            for (int k = 0; k < st.nX; ++k) apply_term(tx[k], w, fr, fi);   // X(0, c)
+                            blo[e] = make_double2(fr, fi);
+                        } else {
+                            for (int k = 0; k < st.nHi - st.nHiD; ++k) apply_term(th[k], w, fr, fi);
+                            bhi[e] = make_double2(fr, fi);
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
 
         // ---- first pass: the product state of the hoisted first gates -----------------------
         // amplitude(w) = prod_q U_q[w_q][0] over the initialised qubits, 0 where a bit of an
         // uninitialised qubit is set; factored over the column / row halves like a diagonal stage
-        if (a.first) {
+        if (hoist) {
+            const DevStage st = a.stages[a.n_init];
+            const RTerm* tld = rt + st.t0 + (st.nLo - st.nLoD);
+            const RTerm* thd = rt + st.t0 + st.nLo + (st.nHi - st.nHiD);
+            const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
+            double2 gs = make_double2((whi & a.zero_in) ? 0.0 : 1.0, 0.0);
+            for (int s = 0; s < a.n_init; ++s) {
+                const int2 g = s_init[s];
+                if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
+            }
+            for (uint32_t j = tid; j < nlo + nhi; j += T) {
+                const bool is_lo = j < nlo;
+                double2 f = is_lo ? cmul(blo[j], gs) : bhi[j - nlo];
+                const uint32_t w = whi | (is_lo ? j : ((j - nlo) << h));
+                if (is_lo) {
+                    for (int k = 0; k < st.nLoD; ++k) apply_term(tld[k], w, f.x, f.y);
+                    tlo[j] = f;
+                } else {
+                    for (int k = 0; k < st.nHiD; ++k) apply_term(thd[k], w, f.x, f.y);
+                    thi[j - nlo] = f;
+                }
+            }
+            __syncthreads();
+        } else if (a.first) {
             const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
             double2 gs = make_double2((whi & a.zero_in) ? 0.0 : 1.0, 0.0);
             for (int s = 0; s < a.n_init; ++s) {
@@ -382,7 +455,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 const bool fused = fuse_init && s == a.n_init;   // tlo / thi hold the product state's factors
                 // work items: the ratio table first (64 columns: a wavefront shares its row bit, so
                 // the term ranges are scalar reads), then the column and the row tables
-                for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
+                if (!(fused && hoist)) for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
                     double fr = 1.0, fi = 0.0;
                     if (j < n_rat) {
                         const uint32_t c = j & (nlo - 1u);
@@ -608,16 +681,21 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.nlive = __builtin_popcount(a.live_chunks);
         if ((N >> (62 - a.nlive)) != 0) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
         a.n_items = N << a.nlive;
+        const bool hoist = ps.first && a.nlive > 0 && ps.n_init > 0 && ps.n_init < ps.n_stage &&
+                           c.stages[ps.stage_off + ps.n_init].kind == ST_DIAG;
+        a.hoist = hoist ? 1 : 0;
         size_t lds = ((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
-                     (size_t)16 * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
+                     (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                      (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1) +
                      (size_t)8 * ps.n_init;
         const size_t stage_bytes = sizeof(DevExpr) * ps.n_expr + sizeof(qk_instr) * c.prog.size() + 8 * c.consts.size();
-        a.staged = lds + stage_bytes <= (size_t)160 * 1024 ? 1 : 0;
+        // stage the programs in LDS unless that costs a resident workgroup
+        const size_t budget = (size_t)160 * 1024;
+        a.staged = (lds + stage_bytes <= budget && budget / (lds + stage_bytes) >= std::min<size_t>(budget / lds, 2)) ? 1 : 0;
         if (a.staged) lds += stage_bytes;
         if (rdm_dev) {
             a.red_off = (int)((lds - (((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
-                                      (size_t)16 * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
+                                      (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                                       (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1))) / 8);
             lds += (size_t)8 * RDM_SLOTS * ((1 << ps.lgT) / 64);
         }
