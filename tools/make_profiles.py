@@ -46,8 +46,9 @@ Summaries made by tools/make_profiles.py.
 | SQ_WAIT_INST_ANY / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY | {gC['SQ_WAIT_INST_ANY']:.4g} / {gC['SQ_WAIT_ANY']:.4g} / {gC['SQ_ACTIVE_INST_ANY']:.4g} | issue-stall (MFMA pipe back-pressure) {gC['SQ_WAIT_INST_ANY']/gC['SQ_WAVE_CYCLES']*100:.0f}% of wave cycles, parked on waitcnt/barrier {gC['SQ_WAIT_ANY']/gC['SQ_WAVE_CYCLES']*100:.0f}% |
 
 The MFMA pipe is busy {util*100:.1f}% of the cycles the GPU was active.  The peak figure of 78.6 TFLOP/s assumes
-2.4 GHz; this box held {cyc/t/1e9:.2f} GHz under the kernel (boxes of the pool differ: 2.09 - 2.38 GHz seen, the
-same launch takes 12.03 s on a 2.38 GHz box; cycle counts agree to 1%).  Cycle for cycle the kernel is at
+2.4 GHz; this box held {cyc/t/1e9:.2f} GHz under the kernel.  Boxes of the pool differ by about 10% on this
+launch (12.03 s on the fastest seen, the same busy-cycle count = 90% there; a 2.09 GHz box was seen too): see
+DESIGN.md section 5.  On this box the kernel is at
 {util*100:.0f}% of the FP64 matrix pipe and, because the 3-multiplication complex product needs 6 instead of 8
 real flops per complex multiply-add, delivers {8/6*util*100:.0f}% of the pipe's peak in algorithmic (8*D per entry) flops.
 
