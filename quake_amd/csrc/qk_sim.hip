@@ -39,7 +39,7 @@ struct SimArgs {
     int L, h, lgT, n_qubits, first;
     uint32_t zero_in, zero_out;  // virtual-bit masks of still-|0> qubits (see Pass)
     int n_init;                  // first pass: leading ST_INIT stages (hoisted first gates)
-    int hoist;                   // per-sample base tables for the fused first diagonal stage (several chunks per sample)
+    int hoist;                   // fused first diagonal stage: 1 = tables built once per sample, 2 = ... as separate base tables (several chunks per sample)
     uint32_t live_chunks;        // chunk-index bits that are not known-zero after the pass
     int nlive;                   // popcount(live_chunks)
     int64_t n_items;             // N << nlive (sample, live chunk) pairs
@@ -243,9 +243,12 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     double2* tlo = mat + 4 * a.n_mat;                       // phase table over local bits < h
     double2* thi = tlo + (1u << h);                         // phase table over local bits >= h
     double2* rat = thi + (1u << (L - h));                   // [row bit][column]: cross-term ratio of setting that bit
-    double2* blo = rat + ((uint32_t)(L - h) << h);          // chunk-independent part of tlo / thi (hoist mode only)
-    double2* bhi = blo + (1u << h);
-    double* xbuf = a.hoist ? (double*)(bhi + (1u << (L - h))) : (double*)blo;   // feature rows of this item and the next
+    double2* tables_end = rat + ((uint32_t)(L - h) << h);
+    // hoist == 2: the chunk-independent part of tlo / thi has its own tables; hoist == 1 (one chunk per
+    // sample): it IS tlo / thi
+    double2* blo = a.hoist == 2 ? tables_end : tlo;
+    double2* bhi = a.hoist == 2 ? blo + (1u << h) : thi;
+    double* xbuf = a.hoist == 2 ? (double*)(bhi + (1u << (L - h))) : (double*)tables_end;   // feature rows of this item and the next
     const int xs = (a.n_params + 1) & ~1;
     DevExpr* s_expr = (DevExpr*)(xbuf + 2 * xs);            // staged angle programs (a.staged)
     qk_instr* s_prog = (qk_instr*)(s_expr + a.n_expr);
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     // Several chunks per sample: what those tables owe to local bits only (the product state's factors,
     // the terms without a chunk bit, the cross-term ratios) is computed once per sample; a chunk
     // multiplies in its scalar and the few terms that read a chunk bit.
-    const bool hoist = a.hoist != 0;    // = fuse_init && a.nlive > 0, decided by the host with the LDS layout
+    const bool hoist = a.hoist != 0;    // = fuse_init, decided by the host with the LDS layout
     int par = 0;
     int64_t angles_of = -1;     // the sample whose (cos, sin) values sit in rt / mat
     for (int64_t item = item_begin; item < item_end; ++item) {
@@ -348,6 +351,16 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 const RTerm* tx = th + st.nHi;
                 const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
                 const uint32_t n_rat = st.nX ? (nlo * (uint32_t)(L - h)) : 0u;
+                // one chunk per sample (hoist == 1): these ARE the stage's tables, chunk-bit terms and
+                // the chunk's scalar included
+                const bool all = a.hoist == 1;
+                const int n_tl = all ? st.nLo : st.nLo - st.nLoD, n_th = all ? st.nHi : st.nHi - st.nHiD;
+                double2 gs = make_double2((all && (whi & a.zero_in)) ? 0.0 : 1.0, 0.0);
+                if (all)
+                    for (int q = 0; q < a.n_init; ++q) {
+                        const int2 g = s_init[q];
+                        if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
+                    }
                 for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
                     double fr = 1.0, fi = 0.0;
                     if (j < n_rat) {
@@ -364,20 +377,20 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                     } else {
                         const bool is_lo = j < n_rat + nlo;
                         const uint32_t e = j - n_rat - (is_lo ? 0u : nlo);
-                        const uint32_t w = is_lo ? e : (e << h);
-                        if (w & a.zero_in) fr = 0.0;
-                        double2 f = make_double2(fr, 0.0);
+                        const uint32_t wl = is_lo ? e : (e << h);
+                        const uint32_t w = all ? (whi | wl) : wl;
+                        double2 f = (wl & a.zero_in) ? make_double2(0.0, 0.0) : (is_lo ? gs : make_double2(1.0, 0.0));
                         for (int q = 0; q < a.n_init; ++q) {
                             const int2 g = s_init[q];
                             if (g.x < L && (g.x < h) == is_lo) f = cmul(f, mat[4 * g.y + 2 * ((w >> g.x) & 1u)]);
                         }
                         fr = f.x; fi = f.y;
                         if (is_lo) {
-                            for (int k = 0; k < st.nLo - st.nLoD; ++k) apply_term(tl[k], w, fr, fi);
+                            for (int k = 0; k < n_tl; ++k) apply_term(tl[k], w, fr, fi);
                             for (int k = 0; k < st.nX; ++k) apply_term(tx[k], w, fr, fi);   // X(0, c)
                             blo[e] = make_double2(fr, fi);
                         } else {
-                            for (int k = 0; k < st.nHi - st.nHiD; ++k) apply_term(th[k], w, fr, fi);
+                            for (int k = 0; k < n_th; ++k) apply_term(th[k], w, fr, fi);
                             bhi[e] = make_double2(fr, fi);
                         }
                     }
@@ -389,7 +402,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         // ---- first pass: the product state of the hoisted first gates -----------------------
         // amplitude(w) = prod_q U_q[w_q][0] over the initialised qubits, 0 where a bit of an
         // uninitialised qubit is set; factored over the column / row halves like a diagonal stage
-        if (hoist) {
+        if (a.hoist == 2) {
             const DevStage st = a.stages[a.n_init];
             const RTerm* tld = rt + st.t0 + (st.nLo - st.nLoD);
             const RTerm* thd = rt + st.t0 + st.nLo + (st.nHi - st.nHiD);
@@ -412,7 +425,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 }
             }
             __syncthreads();
-        } else if (a.first) {
+        } else if (a.first && !hoist) {
             const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
             double2 gs = make_double2((whi & a.zero_in) ? 0.0 : 1.0, 0.0);
             for (int s = 0; s < a.n_init; ++s) {
@@ -681,9 +694,11 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.nlive = __builtin_popcount(a.live_chunks);
         if ((N >> (62 - a.nlive)) != 0) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
         a.n_items = N << a.nlive;
-        const bool hoist = ps.first && a.nlive > 0 && ps.n_init > 0 && ps.n_init < ps.n_stage &&
-                           c.stages[ps.stage_off + ps.n_init].kind == ST_DIAG;
-        a.hoist = hoist ? 1 : 0;
+        // first diagonal stage directly after the product state: its tables are built once per sample
+        const bool fuse = ps.first && ps.n_init > 0 && ps.n_init < ps.n_stage &&
+                          c.stages[ps.stage_off + ps.n_init].kind == ST_DIAG;
+        const bool hoist = fuse && a.nlive > 0;     // several chunks per sample: separate base tables
+        a.hoist = fuse ? (hoist ? 2 : 1) : 0;
         size_t lds = ((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
                      (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                      (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1) +
