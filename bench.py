@@ -214,11 +214,19 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     probe = mfma_probe() if (world == 1 and not a.no_probe) else None   # child process, before this one touches the GPU
+    # QK_BENCH_REHEARSAL=1: rehearse the N>1 code path on a ONE-GPU box -- every rank uses cuda:0 and the
+    # exchanges go over gloo (RCCL refuses two ranks on one device).  Timings of such a run mean nothing.
+    rehearsal = world > 1 and os.environ.get("QK_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from quake_amd import device as qdev, featuremaps as fm, sharded
     from quake_amd.circuit import ParameterVector
@@ -244,7 +252,7 @@ def main():
     psi = torch.empty((N, D), dtype=torch.complex64 if single else torch.complex128, device=dev)
     psi_real = torch.view_as_real(psi).view(N, 2 * D)
     K = torch.empty((r1 - r0, N), dtype=torch.float64, device=dev)
-    sg = sharded.ShardedGram(N, D, rank, world)
+    sg = sharded.ShardedGram(N, D, rank, world, host_staging=rehearsal)
     sg.allocate(dev, torch)
 
     ev = {}
@@ -283,6 +291,17 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    if rehearsal:
+        # the rank's delivered row block against a plain cross block of the same rows (no symmetry, no exchange)
+        Kc = qdev.gram(psi[r0:r1], psi)
+        d = (Kc - K).abs()
+        d[torch.arange(r1 - r0, device=dev), torch.arange(r0, r1, device=dev)] = 0.0   # the diagonal is pinned to exactly 1
+        err = float(d.max())
+        print(f"[rehearsal] rank {rank}: rows {r0}:{r1}, max |K_block - cross block| = {err:.3e}", flush=True)
+        if not err < 1e-12:
+            raise SystemExit(f"rank {rank}: sharded row block differs from the direct cross block")
+        del Kc, d
 
     # configs[4] also names 16384 test rows: the test x train cross block, outside `value`
     test_block = None

@@ -97,9 +97,12 @@ class ShardedGram:
     launcher :func:`quake_amd.device.gram_jobs`."""
 
     def __init__(self, N: int, D: int, rank: int = 0, world: int = 1, group=None,
-                 gram_jobs: Optional[Callable] = None):
+                 gram_jobs: Optional[Callable] = None, host_staging: bool = False):
+        """``host_staging``: exchange the mirrored blocks through host memory (for a backend that cannot
+        send device tensors point to point, e.g. gloo in a one-GPU rehearsal); RCCL sends them directly."""
         check_shape(N, world)
         self.N, self.D, self.rank, self.world, self.group = N, D, rank, world, group
+        self.host_staging = host_staging
         if gram_jobs is None:
             from .device import gram_jobs as hip_gram_jobs
             gram_jobs = hip_gram_jobs
@@ -155,12 +158,19 @@ class ShardedGram:
         if self.world == 1:
             return K_block
         ops = []
-        for buf, t in zip(self._stage["send"], rest):
+        send_bufs, recv_bufs = self._stage["send"], self._stage["recv"]
+        if self.host_staging:
+            send_bufs = [b.cpu() for b in send_bufs]
+            recv_bufs = [torch.empty(b.shape, dtype=b.dtype) for b in recv_bufs]
+        for buf, t in zip(send_bufs, rest):
             ops.append(dist.P2POp(dist.isend, buf, t.peer, group=self.group))
-        for buf, (src, _) in zip(self._stage["recv"], self.recv):
+        for buf, (src, _) in zip(recv_bufs, self.recv):
             ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if self.host_staging:
+            for dst, src in zip(self._stage["recv"], recv_bufs):
+                dst.copy_(src)
         g0, _ = row_range(self.rank, self.world, self.N)
         for buf, (_, t) in zip(self._stage["recv"], self.recv):
             # sender computed rows a0:a1 x my rows b0:b1 and sent the transpose [b, a]
