@@ -163,7 +163,7 @@ def pqk_main(a, rank, world, dev, dist):
         e[0].record()
         rdm = qdev.simulate_rdm1(circ, X)
         e[1].record()
-        K = sharded.sharded_projected_kernel(rdm, 1.0, rank, world)
+        K = sharded.sharded_projected_kernel(rdm, 1.0, rank, world, host_staging=os.environ.get("QK_BENCH_REHEARSAL") == "1")
         e[2].record()
         if timed:
             ev.append(e)
@@ -179,14 +179,24 @@ def pqk_main(a, rank, world, dev, dist):
         step(False)
     fence()
     t0 = time.perf_counter()
+    K = None
     for _ in range(a.steps):
-        step(True)
+        K = step(True)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if world > 1 and K is not None and os.environ.get("QK_BENCH_REHEARSAL") == "1":
+        # the rank's block against one computed from a table this rank built alone
+        Xf = torch.from_numpy(np.random.default_rng(1004).uniform(-np.pi / 2 + 1e-5, np.pi / 2 - 1e-5, size=(N, n))).to(dev)
+        full = qdev.simulate_rdm1(circ, Xf)
+        d = (qdev.pqk(full[r0:r1].contiguous(), full, 1.0) - K).abs()
+        d[torch.arange(r1 - r0, device=dev), torch.arange(r0, r1, device=dev)] = 0.0
+        print(f"[rehearsal] rank {rank}: rows {r0}:{r1}, max |K_block - direct block| = {float(d.max()):.3e}", flush=True)
+        if not float(d.max()) < 1e-12:
+            raise SystemExit(f"rank {rank}: sharded projected-kernel block differs from the direct block")
     if rank == 0:
         sim_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if ev else 0.0
         pair_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if ev else 0.0

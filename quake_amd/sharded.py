@@ -178,7 +178,8 @@ class ShardedGram:
         return K_block
 
 
-def sharded_projected_kernel(rdm_local, gamma: float, rank: int = 0, world: int = 1, group=None, pqk_fn=None):
+def sharded_projected_kernel(rdm_local, gamma: float, rank: int = 0, world: int = 1, group=None, pqk_fn=None,
+                             host_staging: bool = False):
     """Projected-kernel row block on one rank (config 4 of BASELINE.json).
 
     Each rank has simulated its row shard and reduced it to the per-qubit RDM table
@@ -199,7 +200,12 @@ def sharded_projected_kernel(rdm_local, gamma: float, rank: int = 0, world: int 
         pqk_fn(rdm_local, None, gamma, out)
         return out
     table = torch.empty((world * nloc,) + tuple(rdm_local.shape[1:]), dtype=rdm_local.dtype, device=rdm_local.device)
-    dist.all_gather_into_tensor(table, rdm_local, group=group)
+    if host_staging:   # a backend without device collectives (one-GPU rehearsal over gloo)
+        table_host = torch.empty(table.shape, dtype=table.dtype)
+        dist.all_gather_into_tensor(table_host, rdm_local.cpu(), group=group)
+        table.copy_(table_host)
+    else:
+        dist.all_gather_into_tensor(table, rdm_local, group=group)
     out = torch.empty((nloc, world * nloc), dtype=torch.float64, device=rdm_local.device)
     r0 = rank * nloc
     if r0 > 0:
