@@ -59,7 +59,7 @@ def _cpu_gram_jobs(jobs, D):
             j["KT"].copy_(torch.from_numpy(np.ascontiguousarray(K.T)))
 
 
-def _worker(rank, world, port, N, n, replicate=False):
+def _worker(rank, world, port, N, n, replicate=False, host_staging=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -76,7 +76,7 @@ def _worker(rank, world, port, N, n, replicate=False):
             local = torch.from_numpy(O.statevectors(ops, n, X[r0:r1]))
             psi_full[r0:r1] = local
             work = dist.all_gather_into_tensor(psi_full, local, async_op=True)
-        sg = sharded.ShardedGram(N, D, rank, world, gram_jobs=_cpu_gram_jobs)
+        sg = sharded.ShardedGram(N, D, rank, world, gram_jobs=_cpu_gram_jobs, host_staging=host_staging)
         K_block = torch.full((r1 - r0, N), -1.0, dtype=torch.float64)
         sg.compute(psi_full, K_block, gather_work=work)
         ref = O.evaluate(ops, n, X)[r0:r1]
@@ -100,6 +100,11 @@ def test_sharded_gram_over_gloo(world):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_gram_replicated_psi_over_gloo(world):
     mp.spawn(_worker, args=(world, _free_port(), 8 * world, 4, True), nprocs=world, join=True)
+
+
+def test_sharded_gram_host_staged_exchange_over_gloo():
+    """bench.py's one-GPU rehearsal mode: the mirrored blocks travel through host buffers."""
+    mp.spawn(_worker, args=(4, _free_port(), 32, 4, True, True), nprocs=4, join=True)
 
 
 def _cpu_pqk(rdm_x, rdm_y, gamma, out):
