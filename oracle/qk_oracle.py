@@ -355,6 +355,17 @@ def fidelity_kernel(psi_x, psi_y=None, enforce_psd=False):
     if sym:
         psi_y = psi_x
     K = np.abs(psi_x.conj() @ psi_y.T) ** 2
+    # "if np.array_equal(x_sv, y_sv): continue" -- entries of equal statevectors stay exactly 1.0,
+    # on the diagonal, for duplicate rows and for rows shared by x_vec and y_vec
+    kx = [r.tobytes() for r in np.ascontiguousarray(psi_x)]
+    ky = kx if sym else [r.tobytes() for r in np.ascontiguousarray(psi_y)]
+    where = {}
+    for j, k in enumerate(ky):
+        where.setdefault(k, []).append(j)
+    if sym or set(kx) & set(where):
+        for i, k in enumerate(kx):
+            for j in where.get(k, ()):
+                K[i, j] = 1.0
     if sym:
         np.fill_diagonal(K, 1.0)
         if enforce_psd:

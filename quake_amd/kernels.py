@@ -44,6 +44,31 @@ def _as_2d(a, name: str) -> np.ndarray:
     return a
 
 
+def _pin_equal_rows(K: np.ndarray, x: np.ndarray, y: Optional[np.ndarray]) -> None:
+    """The reference leaves ``K[i, j]`` at exactly 1.0 whenever the two statevectors compare equal
+    (FidelityStatevectorKernel._evaluate) -- also off the diagonal (duplicate samples)
+    and in cross blocks (a test row that is also a train row).  Equal input rows give equal
+    statevectors (the simulator is deterministic), so those entries are pinned here; a circuit without
+    parameters maps every row to the same state.  Costs one row sort; does nothing without duplicates."""
+    if x.shape[1] == 0:
+        K.fill(1.0)
+        return
+    def keys(a):
+        a = np.ascontiguousarray(a)
+        return a.view(np.dtype((np.void, a.dtype.itemsize * a.shape[1]))).ravel()
+    kx = keys(x)
+    if y is None:
+        _, inv, counts = np.unique(kx, return_inverse=True, return_counts=True)
+        for g in np.nonzero(counts > 1)[0]:
+            idx = np.nonzero(inv == g)[0]
+            K[np.ix_(idx, idx)] = 1.0
+        return
+    ky = keys(y)
+    common = np.intersect1d(kx, ky)
+    for v in common:
+        K[np.ix_(np.nonzero(kx == v)[0], np.nonzero(ky == v)[0])] = 1.0
+
+
 class HipFidelityKernel:
     """``K[i, j] = |<psi(x_i)|psi(y_j)>|^2`` for a parameterised feature map.
 
@@ -165,6 +190,7 @@ class HipFidelityKernel:
         _lib.check((lib.qk_evaluate if self._precision == "double" else lib.qk_evaluate_f32)(
             circ.handle, _lib.ptr(x), n,
             _lib.ptr(y) if y is not None else None, m, x.shape[1], _lib.ptr(K)))
+        _pin_equal_rows(K, x, y)
         if y is None and self._enforce_psd:
             K = self._make_psd(K)
         return K

@@ -282,6 +282,29 @@ def test_gram_raw_layout_asymmetric():
         assert (S[0] == -1).all() and (S[:, :2] == -1).all() and (S[N + 1:] == -1).all() and (S[:, N + 2:] == -1).all()
 
 
+def test_equal_rows_stay_exactly_one():
+    """FidelityStatevectorKernel skips pairs whose statevectors compare equal, so those entries are
+    exactly 1.0 -- duplicate samples in the symmetric matrix, a test row that is also a train row in
+    a cross block, every entry for a circuit without parameters."""
+    n = 5
+    circ, oops, _ = map_pairs(n, 2)["zz"]
+    X = synth_X(40, n, "scaled", 9)
+    X[7] = X[3]; X[21] = X[3]; X[30] = X[12]
+    Y = synth_X(11, n, "scaled", 10)
+    Y[4] = X[3]; Y[9] = X[0]
+    k = HipFidelityKernel(circ)
+    K, Kref = k.evaluate(X), O.evaluate(oops, n, X)
+    assert np.array_equal(K == 1.0, Kref == 1.0) and (K == 1.0).sum() == 40 + 6 + 2
+    assert np.abs(K - Kref).max() < TOL_K
+    Kc, Kcref = k.evaluate(X, Y), O.evaluate(oops, n, X, Y)
+    assert np.array_equal(Kc == 1.0, Kcref == 1.0) and (Kc == 1.0).sum() == 3 + 1
+    assert np.abs(Kc - Kcref).max() < TOL_K
+    const = qc.QuantumCircuit(3)
+    const.h(0); const.cx(0, 1); const.sx(2)
+    Kone = HipFidelityKernel(const).evaluate(np.zeros((6, 0)))
+    assert Kone.shape == (6, 6) and (Kone == 1.0).all()
+
+
 def test_pinned_output_arrays():
     """Large outputs of the host entry points live in page-locked memory (qk_host_alloc) so that K comes
     back at the PCIe rate; to the caller they are ordinary fresh numpy arrays."""
