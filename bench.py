@@ -126,7 +126,8 @@ def gram_kernel_name(rows, D):
     lib.qk_gram_variant_for.argtypes = [C.c_int64, C.c_int64]
     name = lib.qk_gram_variant_for(rows, D).decode()
     return {"dma3m_128x128_w8": "qk::gram_dma_kernel<2,4,4,2,true> (128x128 tiles)",
-            "dma3m_64x64_w4": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles)"}.get(name, name)
+            "dma3m_64x64_w4": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles)",
+            "dma3m_64x64_w4_g64": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles, 8x8 tile groups)"}.get(name, name)
 
 
 def pmc_traffic(N, n, repeats, world):
@@ -361,7 +362,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK, "unit": "TFLOP/s",
                 "frac": achieved / PEAK, "traffic": None if single else pmc_traffic(N, n, a.repeats, world),
-                "kernel": "qk::gram32_dma_kernel<2,4,4,2>" if single else gram_kernel_name(N // world, D),
+                "kernel": "qk::gram32_dma_kernel<2,2,2,2>" if single else gram_kernel_name(N // world, D),
                 "ms_per_launch_set": gram_ms,
                 "algorithmic_flops": flops_rank,
                 "mfma_flops": 0.75 * flops_rank,

@@ -41,6 +41,7 @@ struct GramJobDev {
     int32_t flags;
     int32_t tiles_m, tiles_n;  // block tiles
     int64_t block_begin;       // first workgroup of this job
+    int64_t live;              // packed schedule: number of tiles that have to be computed (< 0: macro-tile schedule)
 };
 
 struct GramArgs {
@@ -56,6 +57,14 @@ struct GramArgs {
 // time form ONE macro-tile (4 A row blocks, 8 B row blocks), and the 8 XCDs walk neighbouring
 // macro-tiles of the same 4-row band.  A symmetric job lists only macro-tiles that reach the
 // diagonal, so every XCD gets the same number of them (+-1).
+//
+// Packed schedule (J.live >= 0; every job except a symmetric one on non-square tiles): the tiles that
+// have to be computed are listed band by band (a band = 2^lr tile rows), column-major inside a band,
+// and the list is cut into groups of 2^(lr+lc) consecutive tiles -- a 4 x 8 macro-tile again, except
+// that it holds no tile below the diagonal and no tile beyond the edge.  No workgroup returns early
+// (but for the last group of a job), so the 32 workgroups of an XCD keep starting and finishing
+// together and keep sharing their A and B row blocks in L2; with dead tiles in the macro-tiles every
+// one of them shifted a CU by a tile time for the rest of the launch.
 __device__ __forceinline__ bool gram_locate(const GramArgs& args, int BM, int BN, GramJobDev& J, int& ti, int& tj) {
     const int64_t bid = blockIdx.x;
     // constant indices only: a dynamic index into the kernel-argument struct would copy it to scratch
@@ -67,9 +76,47 @@ __device__ __forceinline__ bool gram_locate(const GramArgs& args, int BM, int BN
     const int xcd = (int)(lb & 7);
     const int64_t seq = lb >> 3;                       // position in this XCD's stream
     const int lr = args.lr, lc = args.lc;
-    int64_t mt = (seq >> (lr + lc)) * 8 + xcd;         // macro-tile index within the job
+    int64_t mt = (seq >> (lr + lc)) * 8 + xcd;         // macro-tile (group) index within the job
     const int tin = (int)(seq & ((1 << (lr + lc)) - 1));
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+    if (J.live >= 0) {
+        int64_t t = (mt << (lr + lc)) + tin;           // index in the job's list of live tiles
+        if (t >= J.live) return false;
+        const int br = 1 << lr, TMt = J.tiles_m, TNt = J.tiles_n;
+        if (!sym) {
+            const int64_t per_band = (int64_t)br * TNt;
+            const int band = (int)(t / per_band);
+            const int idx = (int)(t - band * per_band);
+            const int rb = min(br, TMt - band * br);
+            tj = idx / rb;
+            ti = band * br + (idx - tj * rb);
+            return true;
+        }
+        // symmetric, square tiles: band m holds, for the columns c >= m * br, the rows m * br .. min(c, m * br + rb - 1)
+        int m = 0, rb = 0;
+        for (;; ++m) {
+            const int first = m * br;
+            if (first >= TMt) return false;
+            rb = min(br, TMt - first);
+            const int64_t cnt = (int64_t)rb * (TNt - first) - rb * (rb - 1) / 2;
+            if (t < cnt) break;
+            t -= cnt;
+        }
+        const int ragged = rb * (rb - 1) / 2;          // tiles of the first rb - 1 columns (1, 2, ... rows)
+        int k, r;
+        if (t < ragged) {
+            k = 0;
+            while ((k + 1) * (k + 2) / 2 <= (int)t) ++k;
+            r = (int)t - k * (k + 1) / 2;
+        } else {
+            const int64_t u = t - ragged;
+            k = rb - 1 + (int)(u / rb);
+            r = (int)(u % rb);
+        }
+        ti = m * br + r;
+        tj = m * br + k;
+        return true;
+    }
     const int CG = (J.tiles_n + (1 << lc) - 1) >> lc, RG = (J.tiles_m + (1 << lr) - 1) >> lr;
     int R = 0, Cg;
     if (sym) {
@@ -779,19 +826,19 @@ static const Variant kVariants[] = {
     QK_DMA_VARIANT("dma3m_96x128_w8", 2, 4, 3, 2, true, 2, 3),   // BM = 96: 24 rows per wave
     QK_DMA_VARIANT("dma4m_128x128_w8", 2, 4, 4, 2, false, 2, 3),
     QK_DMA_VARIANT("dma3m_64x64_w4", 2, 2, 2, 2, true, 2, 3),    // two independent workgroups per CU
+    QK_DMA_VARIANT("dma3m_64x64_w4_g64", 2, 2, 2, 2, true, 3, 3),  // ... whose 64 tiles per XCD form ONE 8 x 8 group
+    QK_DMA_VARIANT("dma3m_64x64_w4_g4x16", 2, 2, 2, 2, true, 2, 4),
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-// Defaults, from in-process A/B runs (tools/gram_ab.py, tools/shard_ab.py):
-//   kBigVariant   dma3m_128x128_w8  one 8-wave workgroup per CU; best when a block streams >= 48 GiB of
-//                                   statevectors (the single-GPU N = 65536, n = 16 matrix: +1.3 %)
-//   kSmallVariant dma3m_64x64_w4    two independent 4-wave workgroups per CU: one keeps the matrix pipe busy
-//                                   while the other sits at its barrier, and small problems split into 4x as
-//                                   many tiles (N = 4096, n = 8: +34 %; one rank's share of the 8-GPU run: +5 %)
-// Variant 0 serves D < 16.
-constexpr int kBigVariant = 4, kSmallVariant = 7;
-constexpr int64_t kBigBytes = (int64_t)48 << 30;
+// Default, from in-process A/B runs (tools/gram_ab.py, tools/shard_ab.py): dma3m_64x64_w4_g64 for every
+// shape.  Two independent 4-wave workgroups per CU: one keeps the matrix pipe busy while the other sits at
+// its barrier, and small problems split into 4x as many tiles.  With the packed tile schedule (gram_locate)
+// it also wins at the headline size (N = 65536, n = 16: 12.50 s against 13.05 s for dma3m_128x128_w8 on
+// the same box; under the older macro-tile schedule with its dead tiles the 128 x 128 tiles were 1.3 %
+// ahead there).  N = 4096, n = 8: +34 % over 128 x 128.
+constexpr int kDefaultVariant = 8;
 
-static int g_variant = -1;       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = choose per call
+static int g_variant = -1;       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = the default
 static bool g_env_read = false;
 static DeviceOnce g_attr_set[kNumVariants];
 
@@ -803,10 +850,8 @@ static int pick_variant(const qk_gram_job* jobs, int n_jobs, int64_t D) {
                 if (std::strcmp(e, kVariants[v].name) == 0) g_variant = v;
     }
     if (g_variant >= 0) return g_variant;
-    int64_t rows = 0;
-    if (jobs)
-        for (int k = 0; k < n_jobs && k < QK_GRAM_MAX_JOBS; ++k) rows = std::max(rows, std::max(jobs[k].ma, jobs[k].nb));
-    return rows * D * 16 >= kBigBytes ? kBigVariant : kSmallVariant;
+    (void)jobs; (void)n_jobs; (void)D;
+    return kDefaultVariant;
 }
 
 }  // namespace qk
@@ -871,6 +916,26 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
         d.tiles_m = (int32_t)((j.ma + bm - 1) / bm);
         d.tiles_n = (int32_t)((j.nb + bn - 1) / bn);
         d.block_begin = blocks;
+        d.live = -1;
+        static const bool force_macro = getenv("QK_GRAM_SCHED") && std::string(getenv("QK_GRAM_SCHED")) == "macro";   // A/B runs
+        const char* sched_now = getenv("QK_GRAM_SCHED_NOW");   // A/B inside one process (tools)
+        const bool macro = force_macro || (sched_now && sched_now[0] == 'm');
+        if (!(macro && sym) && (!sym || bm == bn)) {   // packed schedule (see gram_locate)
+            const int br = 1 << lr;
+            if (sym) {
+                d.live = 0;
+                for (int first = 0; first < d.tiles_m; first += br) {
+                    const int rb = std::min(br, d.tiles_m - first);
+                    d.live += (int64_t)rb * (d.tiles_n - first) - rb * (rb - 1) / 2;
+                }
+            } else {
+                d.live = (int64_t)d.tiles_m * d.tiles_n;
+            }
+            const int64_t per_group = (int64_t)1 << (lr + lc);
+            const int64_t groups = (d.live + per_group - 1) / per_group;
+            blocks += ((groups + 7) / 8) * 8 * per_group;  // whole rounds of 8 groups, one per XCD label
+            continue;
+        }
         const int CG = (d.tiles_n + (1 << lc) - 1) >> lc, RG = (d.tiles_m + (1 << lr) - 1) >> lr;
         int64_t macros = 0;
         if (sym) {
@@ -956,10 +1021,7 @@ extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D
         env_read = true;
         if (const char* e = std::getenv("QK_GRAM32_TILE")) g_tile32 = std::atoi(e);
     }
-    int64_t rows = 0;
-    if (jobs)
-        for (int k = 0; k < n_jobs && k < QK_GRAM_MAX_JOBS; ++k) rows = std::max(rows, std::max(jobs[k].ma, jobs[k].nb));
-    const bool big = g_tile32 ? g_tile32 == 128 : rows * D * 8 >= kBigBytes / 2;   // measured crossover: between 16 and 32 GiB of complex64
+    const bool big = g_tile32 == 128;   // 64 x 64 tiles measured faster at every size (168 vs 166 TFLOP/s at N = 65536, n = 16)
     return big ? launch_gram32<2, 4, 4, 2>(jobs, n_jobs, D, (hipStream_t)stream)
                : launch_gram32<2, 2, 2, 2>(jobs, n_jobs, D, (hipStream_t)stream);
 }

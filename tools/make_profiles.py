@@ -32,13 +32,13 @@ Command per pass (tools/run_profiles.sh): `rocprofv3 --pmc <counters> -- python3
 (separate runs for FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set, no trace flags, as MI355X_MICROARCH.md prescribes).
 Summaries made by tools/make_profiles.py.
 
-## qk::gram_dma_kernel<2,4,4,2,true> (one launch, {t:.3f} s on this box)
+## qk::gram_dma_kernel<2,2,2,2,true> = dma3m_64x64_w4_g64 (one launch, {t:.3f} s on this box)
 
 | quantity | raw counter | derived |
 |---|---|---|
 | FETCH_SIZE | {gA['FETCH_SIZE']:.6g} KiB | x1024 x2 (gfx950: 16-B/lane loads are tallied at half) = **{fetch:.4g} B** read at the memory side of L2 = {fetch/gA['dur_ns']:.0f} GB/s |
 | WRITE_SIZE | {gB['WRITE_SIZE']:.6g} KiB | x1024 = **{write:.4g} B** (K is N*N*8 = {N*N*8:.4g} B) |
-| compulsory traffic | | Psi once + K once = {alg:.4g} B; the kernel re-reads Psi tiles {fetch/(N*D*16):.0f}x (tile reuse is bounded by L2: the 4x8 macro-tile schedule keeps it at {fetch/gA['dur_ns']/1e3:.2f} TB/s, far under the 8 TB/s HBM roof -- the kernel is MFMA-bound) |
+| compulsory traffic | | Psi once + K once = {alg:.4g} B; the kernel re-reads Psi tiles {fetch/(N*D*16):.0f}x (tile reuse is bounded by L2: the packed 8x8 tile groups keep it at {fetch/gA['dur_ns']/1e3:.2f} TB/s, far under the 8 TB/s HBM roof -- the kernel is MFMA-bound) |
 | GRBM_GUI_ACTIVE | {gC['GRBM_GUI_ACTIVE']:.6g} (sum over 8 XCDs) | {cyc:.4g} cycles = **{cyc/t/1e9:.3f} GHz** sustained shader clock on this box |
 | SQ_INSTS_VALU_MFMA_MOPS_F64 | {gC['SQ_INSTS_VALU_MFMA_MOPS_F64']:.6g} (x512 flops) | **{mfma_flops:.4g} hardware MFMA flops** = 6*D per computed entry (3M product); {mfma_flops/t/1e12:.1f} TFLOP/s |
 | SQ_VALU_MFMA_BUSY_CYCLES | {gC['SQ_VALU_MFMA_BUSY_CYCLES']:.6g} | / (cycles x 1024 SIMDs) = **{util*100:.1f}% MFMA pipe busy** |
