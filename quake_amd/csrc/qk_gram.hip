@@ -41,7 +41,7 @@ struct GramJobDev {
     int32_t flags;
     int32_t tiles_m, tiles_n;  // block tiles
     int64_t block_begin;       // first workgroup of this job
-    int64_t live;              // packed schedule: number of tiles that have to be computed (< 0: macro-tile schedule)
+    int64_t live;              // number of tiles that have to be computed
 };
 
 struct GramArgs {
@@ -55,18 +55,14 @@ struct GramArgs {
 // Workgroups with equal (block id % 8) share an XCD and its L2; the 2^(lr+lc) that run there at a time
 // form ONE group of tiles (2^lr A row blocks x 2^lc B row blocks: 8 x 8 for the default 64 x 64 tiles,
 // two workgroups per CU), and the 8 XCDs walk neighbouring groups of the same band.
-//
-// Packed schedule (J.live >= 0; every job except a symmetric one on non-square tiles): the tiles that
-// have to be computed are listed band by band (a band = 2^lr tile rows), column-major inside a band,
-// and the list is cut into groups of 2^(lr+lc) consecutive tiles -- a macro-tile that holds no tile
-// below the diagonal and no tile beyond the edge.  No workgroup returns early (but for the last group
-// of a job), so the workgroups of an XCD keep starting and finishing together and keep sharing their
-// A and B row blocks in L2.
-// Macro-tile schedule (J.live < 0; symmetric jobs on non-square tiles, QK_GRAM_SCHED=macro for A/B):
-// rectangular macro-tiles, of which a symmetric job lists those that reach the diagonal; workgroups
-// of tiles below the diagonal or beyond the edge return at once -- and every one of them shifts a CU by
-// a tile time for the rest of the launch (measured: -2.3 % at N = 65536, n = 16).
-__device__ __forceinline__ bool gram_locate(const GramArgs& args, int BM, int BN, GramJobDev& J, int& ti, int& tj) {
+// The tiles that have to be computed are listed band by band (a band = 2^lr tile rows), column-major
+// inside a band, and the list is cut into groups of 2^(lr+lc) consecutive tiles -- a macro-tile that holds
+// no tile below the diagonal of a symmetric job and no tile beyond the edge.  No workgroup returns early
+// (but for the last group of a job), so the workgroups of an XCD keep starting and finishing together and
+// keep sharing their A and B row blocks in L2.  (The first version enumerated rectangular macro-tiles and
+// let the workgroups of dead tiles return at once; every one of them shifted a CU by a tile time for the
+// rest of the launch: -2.3 % at N = 65536, n = 16.)
+__device__ __forceinline__ bool gram_locate(const GramArgs& args, GramJobDev& J, int& ti, int& tj) {
     const int64_t bid = blockIdx.x;
     // constant indices only: a dynamic index into the kernel-argument struct would copy it to scratch
     J = args.job[0];
@@ -77,67 +73,43 @@ __device__ __forceinline__ bool gram_locate(const GramArgs& args, int BM, int BN
     const int xcd = (int)(lb & 7);
     const int64_t seq = lb >> 3;                       // position in this XCD's stream
     const int lr = args.lr, lc = args.lc;
-    int64_t mt = (seq >> (lr + lc)) * 8 + xcd;         // macro-tile (group) index within the job
-    const int tin = (int)(seq & ((1 << (lr + lc)) - 1));
-    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
-    if (J.live >= 0) {
-        int64_t t = (mt << (lr + lc)) + tin;           // index in the job's list of live tiles
-        if (t >= J.live) return false;
-        const int br = 1 << lr, TMt = J.tiles_m, TNt = J.tiles_n;
-        if (!sym) {
-            const int64_t per_band = (int64_t)br * TNt;
-            const int band = (int)(t / per_band);
-            const int idx = (int)(t - band * per_band);
-            const int rb = min(br, TMt - band * br);
-            tj = idx / rb;
-            ti = band * br + (idx - tj * rb);
-            return true;
-        }
-        // symmetric, square tiles: band m holds, for the columns c >= m * br, the rows m * br .. min(c, m * br + rb - 1)
-        int m = 0, rb = 0;
-        for (;; ++m) {
-            const int first = m * br;
-            if (first >= TMt) return false;
-            rb = min(br, TMt - first);
-            const int64_t cnt = (int64_t)rb * (TNt - first) - rb * (rb - 1) / 2;
-            if (t < cnt) break;
-            t -= cnt;
-        }
-        const int ragged = rb * (rb - 1) / 2;          // tiles of the first rb - 1 columns (1, 2, ... rows)
-        int k, r;
-        if (t < ragged) {
-            k = 0;
-            while ((k + 1) * (k + 2) / 2 <= (int)t) ++k;
-            r = (int)t - k * (k + 1) / 2;
-        } else {
-            const int64_t u = t - ragged;
-            k = rb - 1 + (int)(u / rb);
-            r = (int)(u % rb);
-        }
-        ti = m * br + r;
-        tj = m * br + k;
+    const int64_t group = (seq >> (lr + lc)) * 8 + xcd;
+    int64_t t = (group << (lr + lc)) + (seq & ((1 << (lr + lc)) - 1));   // index in the job's list of live tiles
+    if (t >= J.live) return false;
+    const int br = 1 << lr, TMt = J.tiles_m, TNt = J.tiles_n;
+    if (!(J.flags & QK_GRAM_SYMMETRIC)) {
+        const int64_t per_band = (int64_t)br * TNt;
+        const int band = (int)(t / per_band);
+        const int idx = (int)(t - band * per_band);
+        const int rb = min(br, TMt - band * br);
+        tj = idx / rb;
+        ti = band * br + (idx - tj * rb);
         return true;
     }
-    const int CG = (J.tiles_n + (1 << lc) - 1) >> lc, RG = (J.tiles_m + (1 << lr) - 1) >> lr;
-    int R = 0, Cg;
-    if (sym) {
-        for (;; ++R) {
-            if (R >= RG) return false;
-            const int cg0 = (int)((((int64_t)R << lr) * BM) / ((int64_t)BN << lc));  // first column group that reaches the diagonal
-            const int cnt = CG - cg0;
-            if (cnt <= 0) return false;
-            if (mt < cnt) { Cg = cg0 + (int)mt; break; }
-            mt -= cnt;
-        }
-    } else {
-        R = (int)(mt / CG);
-        Cg = (int)(mt % CG);
-        if (R >= RG) return false;
+    // symmetric (square tiles): band m holds, for the columns c >= m * br, the rows m * br .. min(c, m * br + rb - 1)
+    int m = 0, rb = 0;
+    for (;; ++m) {
+        const int first = m * br;
+        if (first >= TMt) return false;
+        rb = min(br, TMt - first);
+        const int64_t cnt = (int64_t)rb * (TNt - first) - rb * (rb - 1) / 2;
+        if (t < cnt) break;
+        t -= cnt;
     }
-    ti = (R << lr) + (tin >> lc);
-    tj = (Cg << lc) + (tin & ((1 << lc) - 1));
-    // a symmetric job only needs tiles that reach the diagonal or lie above it
-    return !(ti >= J.tiles_m || tj >= J.tiles_n || (sym && (int64_t)(tj + 1) * BN <= (int64_t)ti * BM));
+    const int ragged = rb * (rb - 1) / 2;              // tiles of the first rb - 1 columns (1, 2, ... rows)
+    int k, r;
+    if (t < ragged) {
+        k = 0;
+        while ((k + 1) * (k + 2) / 2 <= (int)t) ++k;
+        r = (int)t - k * (k + 1) / 2;
+    } else {
+        const int64_t u = t - ragged;
+        k = rb - 1 + (int)(u / rb);
+        r = (int)(u % rb);
+    }
+    ti = m * br + r;
+    tj = m * br + k;
+    return true;
 }
 
 // |.|^2 and the stores.  f64 16x16x4 result layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
@@ -199,7 +171,7 @@ gram_kernel(GramArgs args) {
     extern __shared__ v2d smem[];  // [2 buffers][A: BK x LDA | B: BK x LDB]
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, C::BM, C::BN, J, ti, tj)) return;
+    if (!gram_locate(args, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
 
     const int tid = threadIdx.x;
@@ -408,7 +380,7 @@ gram_dma_kernel(GramArgs args) {
     extern __shared__ v2d smem[];  // [2 buffers][A: BM x 16 | B: BN x 16]
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, C::BM, C::BN, J, ti, tj)) return;
+    if (!gram_locate(args, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
 
     const int tid = threadIdx.x;
@@ -616,7 +588,7 @@ gram32_dma_kernel(GramArgs args) {
     extern __shared__ v4f smem32[];
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, C::BM, C::BN, J, ti, tj)) return;
+    if (!gram_locate(args, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
 
     const int tid = threadIdx.x;
@@ -821,10 +793,7 @@ void launch_dma_variant(const GramArgs& args, unsigned blocks, hipStream_t strea
 static const Variant kVariants[] = {
     QK_VARIANT("4m_128x128_w8_bk8", 2, 4, 4, 2, 8, false),
     QK_VARIANT("4m_128x128_w8_bk16", 2, 4, 4, 2, 16, false),
-    QK_VARIANT("3m_96x128_w8_bk16", 2, 4, 3, 2, 16, true),
-    QK_VARIANT("3m_128x96_w8_bk16", 4, 2, 2, 3, 16, true),
     QK_DMA_VARIANT("dma3m_128x128_w8", 2, 4, 4, 2, true, 2, 3),
-    QK_DMA_VARIANT("dma3m_96x128_w8", 2, 4, 3, 2, true, 2, 3),   // BM = 96: 24 rows per wave
     QK_DMA_VARIANT("dma4m_128x128_w8", 2, 4, 4, 2, false, 2, 3),
     QK_DMA_VARIANT("dma3m_64x64_w4", 2, 2, 2, 2, true, 2, 3),    // two independent workgroups per CU
     QK_DMA_VARIANT("dma3m_64x64_w4_g64", 2, 2, 2, 2, true, 3, 3),  // ... whose 64 tiles per XCD form ONE 8 x 8 group
@@ -837,7 +806,7 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // it also wins at the headline size (N = 65536, n = 16: 12.50 s against 13.05 s for dma3m_128x128_w8 on
 // the same box; under the older macro-tile schedule with its dead tiles the 128 x 128 tiles were 1.3 %
 // ahead there).  N = 4096, n = 8: +34 % over 128 x 128.
-constexpr int kDefaultVariant = 8;
+constexpr int kDefaultVariant = 5;   // dma3m_64x64_w4_g64
 
 static int g_variant = -1;       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = the default
 static bool g_env_read = false;
@@ -917,38 +886,20 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
         d.tiles_m = (int32_t)((j.ma + bm - 1) / bm);
         d.tiles_n = (int32_t)((j.nb + bn - 1) / bn);
         d.block_begin = blocks;
-        d.live = -1;
-        static const bool force_macro = getenv("QK_GRAM_SCHED") && std::string(getenv("QK_GRAM_SCHED")) == "macro";   // A/B runs
-        const char* sched_now = getenv("QK_GRAM_SCHED_NOW");   // A/B inside one process (tools)
-        const bool macro = force_macro || (sched_now && sched_now[0] == 'm');
-        if (!(macro && sym) && (!sym || bm == bn)) {   // packed schedule (see gram_locate)
-            const int br = 1 << lr;
-            if (sym) {
-                d.live = 0;
-                for (int first = 0; first < d.tiles_m; first += br) {
-                    const int rb = std::min(br, d.tiles_m - first);
-                    d.live += (int64_t)rb * (d.tiles_n - first) - rb * (rb - 1) / 2;
-                }
-            } else {
-                d.live = (int64_t)d.tiles_m * d.tiles_n;
-            }
-            const int64_t per_group = (int64_t)1 << (lr + lc);
-            const int64_t groups = (d.live + per_group - 1) / per_group;
-            blocks += ((groups + 7) / 8) * 8 * per_group;  // whole rounds of 8 groups, one per XCD label
-            continue;
-        }
-        const int CG = (d.tiles_n + (1 << lc) - 1) >> lc, RG = (d.tiles_m + (1 << lr) - 1) >> lr;
-        int64_t macros = 0;
+        if (sym && bm != bn) return fail(QK_ERR_INVALID, std::string(who) + ": symmetric jobs need square tiles");
+        const int br = 1 << lr;
         if (sym) {
-            for (int R = 0; R < RG; ++R) {
-                const int cnt = CG - (int)((((int64_t)R << lr) * bm) / ((int64_t)bn << lc));
-                if (cnt <= 0) break;
-                macros += cnt;
+            d.live = 0;
+            for (int first = 0; first < d.tiles_m; first += br) {
+                const int rb = std::min(br, d.tiles_m - first);
+                d.live += (int64_t)rb * (d.tiles_n - first) - rb * (rb - 1) / 2;
             }
         } else {
-            macros = (int64_t)RG * CG;
+            d.live = (int64_t)d.tiles_m * d.tiles_n;
         }
-        blocks += ((macros + 7) / 8) * (8 << (lr + lc));  // whole rounds of 8 macro-tiles, one per XCD label
+        const int64_t per_group = (int64_t)1 << (lr + lc);
+        const int64_t groups = (d.live + per_group - 1) / per_group;
+        blocks += ((groups + 7) / 8) * 8 * per_group;  // whole rounds of 8 groups, one per XCD label
     }
     args.n_jobs = nj;
     if (blocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, std::string(who) + ": too many tiles; split the call");
