@@ -183,6 +183,18 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
     int64_t nbands = std::min<int64_t>(16, N / 1024);   // bands of >= 1024 rows; small problems: one launch, one copy
     if (nbands < 2) nbands = 1;
     const int64_t band = ((N + nbands - 1) / nbands + 127) / 128 * 128;
+    if (nbands == 1) {
+        // small problems (the reference's own sizes): one launch on the null stream behind the simulation,
+        // one blocking copy -- no streams or events to create, the call is latency-bound
+        qk_gram_job job;
+        std::memset(&job, 0, sizeof(job));
+        job.A = dPx; job.B = sym ? dPx : dPy; job.K = K;
+        job.ma = N; job.nb = M; job.ldk = M; job.flags = sym ? QK_GRAM_SYMMETRIC : 0;
+        const int rc1 = launch(&job, 1, D, nullptr);
+        if (rc1) return rc1;
+        QK_HIP(hipMemcpy(K_host, K, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));
+        return QK_OK;
+    }
     hipStream_t compute = nullptr, copy = nullptr;
     std::vector<hipEvent_t> done;
     int rc = QK_OK;

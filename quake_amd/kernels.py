@@ -53,20 +53,32 @@ def _pin_equal_rows(K: np.ndarray, x: np.ndarray, y: Optional[np.ndarray]) -> No
     if x.shape[1] == 0:
         K.fill(1.0)
         return
-    def keys(a):
-        a = np.ascontiguousarray(a)
-        return a.view(np.dtype((np.void, a.dtype.itemsize * a.shape[1]))).ravel()
-    kx = keys(x)
+    # 64-bit hash of every row (wrap-around dot product of its bit patterns with fixed odd multipliers):
+    # numeric sorts instead of row-wise comparisons; candidate pairs are verified bit for bit below
+    mult = (np.arange(1, x.shape[1] + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    def h64(a):
+        return (np.ascontiguousarray(a).view(np.uint64) * mult).sum(axis=1, dtype=np.uint64)
+    hx = h64(x)
+    n = hx.shape[0]
     if y is None:
-        _, inv, counts = np.unique(kx, return_inverse=True, return_counts=True)
-        for g in np.nonzero(counts > 1)[0]:
-            idx = np.nonzero(inv == g)[0]
-            K[np.ix_(idx, idx)] = 1.0
+        if np.unique(hx).size == n:
+            return
+        hy, yy = hx, x
+    else:
+        hy, yy = h64(y), y
+    # all (i, j) with hx[i] == hy[j], without a Python loop: equal hashes are runs of the sorted hy
+    order = np.argsort(hy, kind="stable")
+    ys = hy[order]
+    lo, hi = np.searchsorted(ys, hx, "left"), np.searchsorted(ys, hx, "right")
+    cnt = hi - lo
+    total = int(cnt.sum())
+    if total == 0:
         return
-    ky = keys(y)
-    common = np.intersect1d(kx, ky)
-    for v in common:
-        K[np.ix_(np.nonzero(kx == v)[0], np.nonzero(ky == v)[0])] = 1.0
+    rows = np.repeat(np.arange(n), cnt)
+    within = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    cols = order[np.repeat(lo, cnt) + within]
+    same = (x[rows].view(np.uint64) == yy[cols].view(np.uint64)).all(axis=1)
+    K[rows[same], cols[same]] = 1.0
 
 
 class HipFidelityKernel:
