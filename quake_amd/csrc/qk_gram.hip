@@ -932,7 +932,7 @@ static int launch_gram32(const qk_gram_job* jobs, int n_jobs, int64_t D, hipStre
     using C = GramDmaCfg<WM, WN, TM, TN, true>;
     GramArgs args;
     int64_t blocks = 0;
-    const int rc = build_gram_args(jobs, n_jobs, D, C::BM, C::BN, 2, 3, "qk_gram32_jobs_dev", args, blocks);
+    const int rc = build_gram_args(jobs, n_jobs, D, C::BM, C::BN, C::BM == 64 ? 3 : 2, 3, "qk_gram32_jobs_dev", args, blocks);   // 64 x 64: two workgroups per CU = 8 x 8 groups
     if (rc) return rc;
     if (args.n_jobs == 0) return QK_OK;
     static DeviceOnce attr_set;
