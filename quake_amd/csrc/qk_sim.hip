@@ -39,6 +39,7 @@ struct SimArgs {
     int L, h, lgT, n_qubits, first;
     uint32_t zero_in, zero_out;  // virtual-bit masks of still-|0> qubits (see Pass)
     int n_init;                  // first pass: leading ST_INIT stages (hoisted first gates)
+    int direct;                  // the pass is product state + ONE diagonal stage: amplitudes go straight to HBM, no LDS image
     int hoist;                   // fused first diagonal stage: 1 = tables built once per sample, 2 = ... as separate base tables (several chunks per sample)
     uint32_t live_chunks;        // chunk-index bits that are not known-zero after the pass
     int nlive;                   // popcount(live_chunks)
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     const int L = a.L, h = a.h;
     const uint32_t nloc = 1u << L;
     double2* state = lds;
-    RTerm* rt = (RTerm*)(lds + nloc);                       // n_term resolved diagonal terms
+    RTerm* rt = (RTerm*)(lds + (a.direct ? 0u : nloc));     // n_term resolved diagonal terms (direct mode keeps no state in LDS)
     double2* mat = (double2*)(rt + a.n_term);               // n_mat * 4 complex entries
     double2* tlo = mat + 4 * a.n_mat;                       // phase table over local bits < h
     double2* thi = tlo + (1u << h);                         // phase table over local bits >= h
@@ -330,6 +331,11 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         // amplitudes with a bit of a still-|0> qubit set are zero by construction: never loaded
         const uint32_t chunk_phys = deposit(whi, a);
         double2* gpsi = a.psi + sample * a.D;
+        auto store_direct = [&](uint32_t l, double2 v) {     // direct mode: the one place an amplitude is written
+            const int64_t at = chunk_phys | deposit(l, a);
+            if (a.psi32) (a.psi32 + sample * a.D)[at] = make_float2((float)v.x, (float)v.y);
+            else gpsi[at] = v;
+        };
         if (!a.first) {
             if (whi & a.zero_in) {
                 for (uint32_t l = tid; l < nloc; l += T) state[l] = make_double2(0.0, 0.0);
@@ -495,7 +501,9 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 }
                 __syncthreads();
                 if (st.nX == 0) {
-                    if (fused) {
+                    if (fused && a.direct) {
+                        for (uint32_t l = tid; l < nloc; l += T) store_direct(l, cmul(tlo[l & (nlo - 1u)], thi[l >> h]));
+                    } else if (fused) {
                         for (uint32_t l = tid; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
                     } else {
                         for (uint32_t l = tid; l < nloc; l += T) {
@@ -528,7 +536,8 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         const uint32_t r = r0 | g;
                         const double2 f = cmul(X, thi[r]);
                         const uint32_t l = (r << h) | c;
-                        state[l] = fused ? f : cmul(state[l], f);
+                        if (fused && a.direct) store_direct(l, f);
+                        else state[l] = fused ? f : cmul(state[l], f);
                     }
                 }
             } else if (st.kind == ST_U1) {
@@ -586,7 +595,9 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             for (int t = tid + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
         __syncthreads();
         if constexpr (RDM) rdm1_from_lds(state, L, s_red, a.rdm + sample * (L * 4), tid, T);
-        if (a.psi32) {      // only on the last pass: intermediate passes stay FP64
+        if (a.direct) {
+            // already stored by the diagonal stage
+        } else if (a.psi32) {      // only on the last pass: intermediate passes stay FP64
             float2* g32 = a.psi32 + sample * a.D;
             for (uint32_t l = tid; l < nloc; l += T) {
                 const double2 v = state[l];
@@ -699,7 +710,10 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
                           c.stages[ps.stage_off + ps.n_init].kind == ST_DIAG;
         const bool hoist = fuse && a.nlive > 0;     // several chunks per sample: separate base tables
         a.hoist = fuse ? (hoist ? 2 : 1) : 0;
-        size_t lds = ((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
+        // nothing but the product state and one diagonal stage (Z / ZZ maps at r = 1): no LDS image of the state
+        const bool direct = fuse && ps.n_stage == ps.n_init + 1 && !rdm_dev && ps.zero_out == 0 && pi + 1 == c.passes.size();
+        a.direct = direct ? 1 : 0;
+        size_t lds = (direct ? (size_t)0 : ((size_t)16 << ps.L)) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
                      (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                      (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1) +
                      (size_t)8 * ps.n_init;
@@ -717,14 +731,16 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         if (lds > (size_t)160 * 1024) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: pass tables exceed LDS");
         const int threads = 1 << ps.lgT;
         // resident workgroups per CU: LDS, and registers (MAXG = 3: 2 waves/SIMD; MAXG = 2: 3 waves/SIMD)
-        const int by_regs = ((ps.maxg >= 3 || rdm_dev) ? 512 : 768) / threads;
+        // a direct pass has no butterflies: the 256-thread instantiation (3 waves/SIMD) serves it whatever L is
+        const int maxg = (direct && threads <= 256) ? 2 : ps.maxg;
+        const int by_regs = ((maxg >= 3 || rdm_dev) ? 512 : 768) / threads;
         int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)by_regs);
         per_cu = std::max(1, std::min(per_cu, 16));
         const int64_t nblocks = std::min<int64_t>(a.n_items, (int64_t)256 * per_cu);
         const dim3 grid((unsigned)nblocks), block(threads);
-        if (rdm_dev && ps.maxg >= 3) hipLaunchKernelGGL((sim_pass_kernel<3, true>), grid, block, lds, (hipStream_t)stream, a);
+        if (rdm_dev && maxg >= 3) hipLaunchKernelGGL((sim_pass_kernel<3, true>), grid, block, lds, (hipStream_t)stream, a);
         else if (rdm_dev) hipLaunchKernelGGL((sim_pass_kernel<2, true>), grid, block, lds, (hipStream_t)stream, a);
-        else if (ps.maxg >= 3) hipLaunchKernelGGL((sim_pass_kernel<3, false>), grid, block, lds, (hipStream_t)stream, a);
+        else if (maxg >= 3) hipLaunchKernelGGL((sim_pass_kernel<3, false>), grid, block, lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((sim_pass_kernel<2, false>), grid, block, lds, (hipStream_t)stream, a);
         QK_HIP(hipGetLastError());
     }
