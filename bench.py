@@ -310,7 +310,7 @@ def main():
         d[torch.arange(r1 - r0, device=dev), torch.arange(r0, r1, device=dev)] = 0.0   # the diagonal is pinned to exactly 1
         err = float(d.max())
         print(f"[rehearsal] rank {rank}: rows {r0}:{r1}, max |K_block - cross block| = {err:.3e}", flush=True)
-        if not err < 1e-12:
+        if not err < (1e-5 if single else 1e-12):
             raise SystemExit(f"rank {rank}: sharded row block differs from the direct cross block")
         del Kc, d
 
