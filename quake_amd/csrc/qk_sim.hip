@@ -40,6 +40,7 @@ struct SimArgs {
     uint32_t zero_in, zero_out;  // virtual-bit masks of still-|0> qubits (see Pass)
     int n_init;                  // first pass: leading ST_INIT stages (hoisted first gates)
     int direct;                  // the pass is product state + ONE diagonal stage: amplitudes go straight to HBM, no LDS image
+    int last_direct;             // the last stage of the last pass is diagonal: its sweep stores to HBM instead of LDS
     int hoist;                   // fused first diagonal stage: 1 = tables built once per sample, 2 = ... as separate base tables (several chunks per sample)
     uint32_t live_chunks;        // chunk-index bits that are not known-zero after the pass
     int nlive;                   // popcount(live_chunks)
@@ -472,6 +473,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 const uint32_t nlo = 1u << h, nhi = 1u << nrb;
                 const uint32_t n_rat = st.nX ? (nlo * (uint32_t)nrb) : 0u;
                 const bool fused = fuse_init && s == a.n_init;   // tlo / thi hold the product state's factors
+                const bool to_hbm = a.direct || (a.last_direct && s == a.n_stage - 1);   // this sweep produces the final amplitudes
                 // work items: the ratio table first (64 columns: a wavefront shares its row bit, so
                 // the term ranges are scalar reads), then the column and the row tables
                 if (!(fused && hoist)) for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
@@ -501,15 +503,16 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 }
                 __syncthreads();
                 if (st.nX == 0) {
-                    if (fused && a.direct) {
+                    if (fused && to_hbm) {
                         for (uint32_t l = tid; l < nloc; l += T) store_direct(l, cmul(tlo[l & (nlo - 1u)], thi[l >> h]));
                     } else if (fused) {
                         for (uint32_t l = tid; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
                     } else {
                         for (uint32_t l = tid; l < nloc; l += T) {
                             const double2 f0 = tlo[l & (nlo - 1u)], f1 = thi[l >> h];
-                            const double2 v = state[l];
-                            state[l] = cmul(v, cmul(f0, f1));
+                            const double2 v = cmul(state[l], cmul(f0, f1));
+                            if (to_hbm) store_direct(l, v);
+                            else state[l] = v;
                         }
                     }
                 } else {
@@ -536,8 +539,9 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         const uint32_t r = r0 | g;
                         const double2 f = cmul(X, thi[r]);
                         const uint32_t l = (r << h) | c;
-                        if (fused && a.direct) store_direct(l, f);
-                        else state[l] = fused ? f : cmul(state[l], f);
+                        const double2 v = fused ? f : cmul(state[l], f);
+                        if (to_hbm) store_direct(l, v);
+                        else state[l] = v;
                     }
                 }
             } else if (st.kind == ST_U1) {
@@ -595,8 +599,8 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             for (int t = tid + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
         __syncthreads();
         if constexpr (RDM) rdm1_from_lds(state, L, s_red, a.rdm + sample * (L * 4), tid, T);
-        if (a.direct) {
-            // already stored by the diagonal stage
+        if (a.direct || a.last_direct) {
+            // already stored by the (last) diagonal stage
         } else if (a.psi32) {      // only on the last pass: intermediate passes stay FP64
             float2* g32 = a.psi32 + sample * a.D;
             for (uint32_t l = tid; l < nloc; l += T) {
@@ -713,6 +717,8 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         // nothing but the product state and one diagonal stage (Z / ZZ maps at r = 1): no LDS image of the state
         const bool direct = fuse && ps.n_stage == ps.n_init + 1 && !rdm_dev && ps.zero_out == 0 && pi + 1 == c.passes.size();
         a.direct = direct ? 1 : 0;
+        a.last_direct = (!direct && !rdm_dev && ps.zero_out == 0 && pi + 1 == c.passes.size() && ps.n_stage > 0 &&
+                         c.stages[ps.stage_off + ps.n_stage - 1].kind == ST_DIAG) ? 1 : 0;
         size_t lds = (direct ? (size_t)0 : ((size_t)16 << ps.L)) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
                      (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                      (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1) +
