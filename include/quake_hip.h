@@ -79,6 +79,16 @@ int qk_host_alloc(size_t bytes, void** out);
 int qk_host_free(void* p);
 
 /*
+ * No counterpart in the reference (its K is born in host memory): the "K block gathered to host" leg of
+ * the multi-GPU path (BASELINE.json north_star).  Enqueues the copy of a rows x cols float64 block of a
+ * device matrix (row stride ldk elements) into host memory (row stride ldh) on `stream` and returns;
+ * with K_host in page-locked memory (qk_host_alloc, or a pinned torch tensor) the copy overlaps kernels
+ * and exchanges on other streams.  The caller synchronises the stream before reading K_host.
+ */
+int qk_block_to_host_async(const double* K_dev, int64_t ldk, int64_t rows, int64_t cols,
+                           double* K_host, int64_t ldh, void* stream);
+
+/*
  * Replaces: building a qiskit QuantumCircuit over a ParameterVector
  * (reference quantum_featuremaps.py:9-387, genetic_v3.py:363-448) plus
  * QuantumCircuit.assign_parameters: angle program e reads data

@@ -54,6 +54,7 @@ SIGNATURES = {
     "qk_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "qk_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "qk_host_free": (C.c_int, [C.c_void_p]),
+    "qk_block_to_host_async": (C.c_int, [_P, _I64, _I64, _I64, _P, _I64, _P]),
     "qk_circuit_create": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
                                     C.POINTER(_P)]),
     "qk_circuit_destroy": (None, [_P]),

@@ -143,6 +143,18 @@ extern "C" int qk_host_free(void* p) {
     return QK_OK;
 }
 
+extern "C" int qk_block_to_host_async(const double* K_dev, int64_t ldk, int64_t rows, int64_t cols, double* K_host,
+                                      int64_t ldh, void* stream) {
+    using namespace qk;
+    if (rows < 0 || cols < 0) return fail(QK_ERR_INVALID, "qk_block_to_host_async: negative block size");
+    if (rows == 0 || cols == 0) return QK_OK;
+    if (!K_dev || !K_host) return fail(QK_ERR_INVALID, "qk_block_to_host_async: null pointer");
+    if (ldk < cols || ldh < cols) return fail(QK_ERR_INVALID, "qk_block_to_host_async: row stride smaller than the block");
+    QK_HIP(hipMemcpy2DAsync(K_host, (size_t)ldh * sizeof(double), K_dev, (size_t)ldk * sizeof(double),
+                            (size_t)cols * sizeof(double), (size_t)rows, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return QK_OK;
+}
+
 extern "C" int qk_simulate(const qk_circuit* c, const double* X, int64_t N, int64_t ldx, void* psi_host) {
     if (!c || !psi_host) return fail(QK_ERR_INVALID, "qk_simulate: null pointer");
     if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate: negative N");

@@ -127,6 +127,26 @@ def gram(psi_x: torch.Tensor, psi_y: Optional[torch.Tensor] = None, out: Optiona
     return out
 
 
+def block_to_host(K_dev: torch.Tensor, K_host: torch.Tensor, stream: Optional["torch.cuda.Stream"] = None) -> None:
+    """Enqueue the copy of a 2-D float64 device view (unit column stride) into a host view of the same
+    shape (page-locked memory for a copy that overlaps other streams) on ``stream`` (default: torch's
+    current stream): ``qk_block_to_host_async``, one strided copy, no temporaries."""
+    _require_gpu(K_dev)
+    if K_host.is_cuda or K_dev.dtype != torch.float64 or K_host.dtype != torch.float64:
+        raise ValueError("block_to_host copies a float64 device view into a float64 host view")
+    if K_dev.dim() != 2 or tuple(K_dev.shape) != tuple(K_host.shape):
+        raise ValueError("device and host views must be 2-D and of one shape")
+    rows, cols = K_dev.shape
+    if rows == 0 or cols == 0:
+        return
+    if K_dev.stride(1) != 1 or K_host.stride(1) != 1:
+        raise ValueError("both views need unit column stride")
+    s = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+    _lib.check(_lib.load().qk_block_to_host_async(
+        _dp(K_dev), K_dev.stride(0) if rows > 1 else cols, rows, cols,
+        C.c_void_p(K_host.data_ptr()), K_host.stride(0) if rows > 1 else cols, s))
+
+
 def rdm1(psi: torch.Tensor, n_qubits: int) -> torch.Tensor:
     """Per-qubit reduced density matrices, float64 [N, n, 4] = (rho00, rho11, Re rho01, Im rho01)."""
     _require_gpu(psi)

@@ -92,6 +92,30 @@ def computed_entries(rank: int, world: int, N: int) -> int:
     return n
 
 
+class HipHostCopier:
+    """The K-block -> host leg on a side stream (``qk_block_to_host_async``): ``fence()`` orders the side
+    stream behind everything enqueued so far on torch's current stream, ``copy`` enqueues one strided
+    block copy there, ``finish`` waits for the copies.  CPU rehearsals pass an object with the same three
+    methods."""
+
+    def __init__(self):
+        import torch
+        self._torch = torch
+        self.stream = torch.cuda.Stream()
+
+    def fence(self):
+        ev = self._torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+
+    def copy(self, dev_view, host_view):
+        from .device import block_to_host
+        block_to_host(dev_view, host_view, self.stream)
+
+    def finish(self):
+        self.stream.synchronize()
+
+
 class ShardedGram:
     """Executes the plan on torch tensors.  ``gram_jobs(jobs, D)`` defaults to the HIP
     launcher :func:`quake_amd.device.gram_jobs`."""
@@ -132,14 +156,22 @@ class ShardedGram:
             jobs.append(job)
         return jobs
 
-    def compute(self, psi_full, K_block, gather_work=None, timer=None):
+    def compute(self, psi_full, K_block, gather_work=None, timer=None, K_host=None, copier=None):
         """psi_full: complex128 [N, D] (own shard valid; the rest valid once ``gather_work``
-        completes).  K_block: float64 [N/G, N], fully written on return."""
+        completes).  K_block: float64 [N/G, N], fully written on return.
+        K_host: optional host ``[N/G, N]`` float64 (page-locked): the rank's row block is also delivered
+        there -- the blocks this rank computed itself are copied while the mirrored blocks are still
+        travelling between the GPUs, the received ones once they have landed.  Complete on return."""
         import torch
         import torch.distributed as dist
 
         if self._stage is None:
             self.allocate(K_block.device, torch)
+        if K_host is not None:
+            if tuple(K_host.shape) != tuple(K_block.shape):
+                raise ValueError("K_host must have the shape of K_block")
+            if copier is None:
+                copier = self._copier = getattr(self, "_copier", None) or HipHostCopier()
         sends = list(self._stage["send"])
         diag = [t for t in self.tasks if t.symmetric]
         rest = [t for t in self.tasks if not t.symmetric]
@@ -155,7 +187,14 @@ class ShardedGram:
             if rest:
                 self._gram_jobs(self._jobs(psi_full, K_block, rest, sends), self.D)
         if timer: timer("gram_end")
+        g0, _ = row_range(self.rank, self.world, self.N)
+        if K_host is not None:
+            copier.fence()          # behind the Gram launches
+            for t in self.tasks:    # what this rank computed itself (the diagonal block holds its own mirror)
+                copier.copy(K_block[t.a0 - g0:t.a1 - g0, t.b0:t.b1], K_host[t.a0 - g0:t.a1 - g0, t.b0:t.b1])
         if self.world == 1:
+            if K_host is not None:
+                copier.finish()
             return K_block
         ops = []
         send_bufs, recv_bufs = self._stage["send"], self._stage["recv"]
@@ -171,10 +210,14 @@ class ShardedGram:
         if self.host_staging:
             for dst, src in zip(self._stage["recv"], recv_bufs):
                 dst.copy_(src)
-        g0, _ = row_range(self.rank, self.world, self.N)
         for buf, (_, t) in zip(self._stage["recv"], self.recv):
             # sender computed rows a0:a1 x my rows b0:b1 and sent the transpose [b, a]
             K_block[t.b0 - g0:t.b1 - g0, t.a0:t.a1].copy_(buf)
+        if K_host is not None:
+            copier.fence()          # behind the placement of the received blocks
+            for _, t in self.recv:
+                copier.copy(K_block[t.b0 - g0:t.b1 - g0, t.a0:t.a1], K_host[t.b0 - g0:t.b1 - g0, t.a0:t.a1])
+            copier.finish()
         return K_block
 
 

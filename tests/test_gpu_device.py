@@ -94,3 +94,24 @@ def test_fused_simulate_rdm1(n, N, fused):
     assert np.abs(got - want).max() < 1e-13
     two_step = qdev.rdm1(circ.simulate(Xd), n).cpu().numpy()
     assert np.abs(got - two_step).max() < 1e-15
+
+
+def test_k_block_to_host_leg():
+    """ShardedGram.compute(K_host=...): the row block also lands in page-locked host memory through
+    qk_block_to_host_async on a side stream (strided 2-D copies, no temporaries)."""
+    from quake_amd import _lib, sharded
+    n, N = 7, 520
+    torch, dev, circ, oops, X = _setup(n, N, "zz_featuremap", 1)
+    psi = circ.simulate(torch.from_numpy(X).cuda())
+    K = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    K_host = torch.from_numpy(_lib.host_empty((N, N)))
+    K_host.fill_(-3.0)
+    sharded.ShardedGram(N, 1 << n, 0, 1).compute(psi, K, K_host=K_host)
+    assert torch.equal(K_host, K.cpu())
+    assert np.abs(K_host.numpy() - O.evaluate(oops, n, X)).max() < 1e-12
+    # a strided sub-block into a strided host view; everything around it untouched
+    host = torch.full((40, 90), -1.0, dtype=torch.float64)
+    dev.block_to_host(K[100:130, 7:57], host[5:35, 20:70])
+    torch.cuda.synchronize()
+    assert torch.equal(host[5:35, 20:70], K[100:130, 7:57].cpu())
+    assert (host[:5] == -1).all() and (host[35:] == -1).all() and (host[:, :20] == -1).all() and (host[:, 70:] == -1).all()

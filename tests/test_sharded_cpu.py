@@ -59,7 +59,23 @@ def _cpu_gram_jobs(jobs, D):
             j["KT"].copy_(torch.from_numpy(np.ascontiguousarray(K.T)))
 
 
-def _worker(rank, world, port, N, n, replicate=False, host_staging=False):
+class _CpuCopier:
+    """Stand-in for sharded.HipHostCopier (a side stream on the GPU): copies at once, counts the calls."""
+    def __init__(self):
+        self.fences, self.copies, self.finished = 0, 0, 0
+
+    def fence(self):
+        self.fences += 1
+
+    def copy(self, dev_view, host_view):
+        host_view.copy_(dev_view)
+        self.copies += 1
+
+    def finish(self):
+        self.finished += 1
+
+
+def _worker(rank, world, port, N, n, replicate=False, host_staging=False, k_host=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -78,10 +94,16 @@ def _worker(rank, world, port, N, n, replicate=False, host_staging=False):
             work = dist.all_gather_into_tensor(psi_full, local, async_op=True)
         sg = sharded.ShardedGram(N, D, rank, world, gram_jobs=_cpu_gram_jobs, host_staging=host_staging)
         K_block = torch.full((r1 - r0, N), -1.0, dtype=torch.float64)
-        sg.compute(psi_full, K_block, gather_work=work)
+        K_host = torch.full((r1 - r0, N), -2.0, dtype=torch.float64) if k_host else None
+        copier = _CpuCopier() if k_host else None
+        sg.compute(psi_full, K_block, gather_work=work, K_host=K_host, copier=copier)
         ref = O.evaluate(ops, n, X)[r0:r1]
         err = np.abs(K_block.numpy() - ref).max()
         assert err < 1e-13, err
+        if k_host:   # the K block -> host leg delivers every entry of the row block exactly once
+            assert torch.equal(K_host, K_block)
+            assert copier.copies == len(sg.tasks) + len(sg.recv) and copier.finished == 1
+            assert copier.fences == (2 if world > 1 else 1)
     finally:
         dist.destroy_process_group()
 
@@ -105,6 +127,15 @@ def test_sharded_gram_replicated_psi_over_gloo(world):
 def test_sharded_gram_host_staged_exchange_over_gloo():
     """bench.py's one-GPU rehearsal mode: the mirrored blocks travel through host buffers."""
     mp.spawn(_worker, args=(4, _free_port(), 32, 4, True, True), nprocs=4, join=True)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_gram_k_block_to_host_over_gloo(world):
+    mp.spawn(_worker, args=(world, _free_port(), 8 * world, 4, True, False, True), nprocs=world, join=True)
+
+
+def test_k_block_to_host_single_rank():
+    _worker(0, 1, _free_port(), 12, 3, True, False, True)
 
 
 def _cpu_pqk(rdm_x, rdm_y, gamma, out):
