@@ -230,6 +230,19 @@ int qk_kernel_stats_dev(const double* K_dev, int64_t N, int64_t ldk, const int32
                         double* stats_dev, double* workspace_dev, void* stream);
 
 /*
+ * No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops such as a GA fitness loop, harnesses that forbid hipMalloc): the same
+ * statistics as qk_kernel_stats_dev, bitwise, with the partial sums kept in a static device array inside
+ * the library (QK_STATS_WS float64 = 64 KiB per GPU, held until the process ends) instead of a caller
+ * workspace.  Calls no hipMalloc / hipFree.  N above QK_STATS_NOALLOC_MAX_N is refused
+ * (QK_ERR_UNSUPPORTED).  All calls on one GPU share that array: calls that overlap on one GPU (two
+ * streams, two threads) race -- serialise them, or use qk_kernel_stats_dev with a workspace per stream.
+ */
+#define QK_STATS_NOALLOC_MAX_N 131072
+int qk_kernel_stats_noalloc_dev(const double* K_dev, int64_t N, int64_t ldk, const int32_t* labels_dev,
+                                double* stats_dev, void* stream);
+
+/*
  * Replaces: the noise models the reference puts on a statevector kernel matrix, applied in
  * place to a symmetric device K (upper triangle drawn, mirrored, diagonal untouched):
  *   QK_NOISE_GAUSSIAN  K_ij <- clip(K_ij + N(0, param), 0, 1)        (genetic_v3.py:620-627)

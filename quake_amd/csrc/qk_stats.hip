@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "qk_common.h"
@@ -149,6 +150,58 @@ extern "C" int qk_kernel_stats_dev(const double* K, int64_t N, int64_t ldk, cons
                        workspace);
     hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(kStatThreads), 0, (hipStream_t)stream, workspace, blocks, labels, N,
                        stats);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+// ---- the entry point that allocates nothing -------------------------------------------------------
+// The partial sums of stats_partial_kernel (the `workspace` of qk_kernel_stats_dev) live in a file-scope
+// device array instead: QK_STATS_WS doubles = 64 KiB per GPU the library runs on, held until the process
+// ends.  In host code the array's NAME is only a stand-in (passing it to a kernel would fault on the GPU):
+// its address on a device comes from hipGetSymbolAddress, asked once per device with that device current,
+// and only that pointer is ever handed to the kernels.
+static __device__ __align__(256) double scratch[QK_STATS_WS];
+
+namespace qk {
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+double* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// the scratch array's address on the current device (looked up on the first call there)
+int scratch_on_current_device(double** out) {
+    int dev = -1;
+    QK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(QK_ERR_UNSUPPORTED, "qk_kernel_stats_noalloc_dev: device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        QK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(QK_ERR_HIP, "qk_kernel_stats_noalloc_dev: hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = (double*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return QK_OK;
+}
+}  // namespace
+}  // namespace qk
+
+extern "C" int qk_kernel_stats_noalloc_dev(const double* K, int64_t N, int64_t ldk, const int32_t* labels, double* stats,
+                                           void* stream) {
+    if (!K || !stats) return fail(QK_ERR_INVALID, "qk_kernel_stats_noalloc_dev: null pointer");
+    if (N < 1 || ldk < N) return fail(QK_ERR_INVALID, "qk_kernel_stats_noalloc_dev: bad shape");
+    if (N > QK_STATS_NOALLOC_MAX_N)
+        return fail(QK_ERR_UNSUPPORTED, "qk_kernel_stats_noalloc_dev: N exceeds QK_STATS_NOALLOC_MAX_N (131072 rows); "
+                                        "use qk_kernel_stats_dev with a caller-provided workspace");
+    double* ws = nullptr;
+    const int rc = scratch_on_current_device(&ws);
+    if (rc) return rc;
+    // same kernels, same block count and reduction tree as qk_kernel_stats_dev: bitwise the same sums.
+    // Every partial the final kernel reads is written by the partial kernel of THIS call (blocks entries),
+    // so nothing left over from an earlier, larger call is ever read and nothing has to be cleared.
+    const int blocks = (int)std::min<int64_t>(N, kStatMaxBlocks);
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(blocks), dim3(kStatThreads), 0, (hipStream_t)stream, K, N, ldk, labels, ws);
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(kStatThreads), 0, (hipStream_t)stream, ws, blocks, labels, N, stats);
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
