@@ -62,8 +62,52 @@ def test_config5_headline_size():
     d = (Kc - K[band[0]:band[-1] + 1]).abs()
     d[torch.arange(band.numel(), device="cuda"), band] = 0.0       # the symmetric job pins its diagonal to exactly 1
     assert float(d.max()) < 1e-13
-    del K, Kc, psi, d
+    del K, Kc, d
     torch.cuda.empty_cache()
+    # configs[4]'s second half: the 16384 x 65536 test x train block, all of it computed, checked on sampled
+    # test rows x sampled train rows (matrix corners, tile borders) against the oracle
+    T = 16384
+    Xt_host = np.random.default_rng(2005).uniform(LO, HI, size=(T, n))
+    psi_t = circ.simulate(torch.from_numpy(Xt_host).cuda())
+    Kt = qdev.gram(psi_t, psi)
+    torch.cuda.synchronize()
+    assert tuple(Kt.shape) == (T, N) and float(Kt.min()) >= 0.0 and float(Kt.max()) <= 1.0 + 1e-12
+    trows = _sample_rows(T)
+    ref_t = O.statevectors(O.zz_featuremap(n, 1), n, Xt_host[trows])
+    want = np.abs(ref_t.conj() @ ref_psi.T) ** 2
+    got = Kt[torch.from_numpy(trows).cuda()][:, idx].cpu().numpy()
+    assert np.abs(got - want).max() < 1e-12
+    # every row of the block sums to what a second pass over the same operands gives (no tile skipped or doubled):
+    # sum_j K[t, j] recomputed from a transposed job (train x test) on a band of columns
+    Ktt = qdev.gram(psi[N - 2048:], psi_t)                       # [2048, T]
+    assert float((Ktt.T - Kt[:, N - 2048:]).abs().max()) < 1e-13
+    del Kt, Ktt, psi_t, psi
+    torch.cuda.empty_cache()
+
+
+def test_host_entry_point_bands_and_mirror():
+    """HipFidelityKernel.evaluate (numpy in, page-locked numpy out) at 32768 rows: the host path computes K in
+    16 row bands, copies each to the host while the next is computed, and fills the mirror entries of later
+    bands from transposed copies.  Properties on the whole matrix, oracle parity on sampled rows."""
+    from quake_amd.kernels import HipFidelityKernel
+    N, n = 32768, 10
+    X = np.random.default_rng(1010).uniform(LO, HI, size=(N, n))
+    X[N - 5] = X[7]                                              # a duplicate sample: entry pinned to exactly 1
+    K = HipFidelityKernel(fm.zz_featuremap(ParameterVector("x", n), n, 2)).evaluate(X)
+    assert K.shape == (N, N) and K.flags["C_CONTIGUOUS"]
+    assert (np.diagonal(K) == 1.0).all() and K[N - 5, 7] == 1.0 and K[7, N - 5] == 1.0
+    for r0 in range(0, N, 4096):
+        assert np.array_equal(K[r0:r0 + 4096], K[:, r0:r0 + 4096].T), r0
+    rows = _sample_rows(N)
+    ref_psi = O.statevectors(O.zz_featuremap(n, 2), n, X[rows])
+    ref = np.abs(ref_psi.conj() @ ref_psi.T) ** 2
+    np.fill_diagonal(ref, 1.0)
+    assert np.abs(K[np.ix_(rows, rows)] - ref).max() < 1e-12
+    # a cross call (test x train) through the same banded path
+    Y = np.random.default_rng(1011).uniform(LO, HI, size=(3000, n))
+    Kc = HipFidelityKernel(fm.zz_featuremap(ParameterVector("x", n), n, 2)).evaluate(Y, X)
+    ref_y = O.statevectors(O.zz_featuremap(n, 2), n, Y[:40])
+    assert np.abs(Kc[:40][:, rows] - np.abs(ref_y.conj() @ ref_psi.T) ** 2).max() < 1e-12
 
 
 def test_config4_projected_kernel_full_size():
@@ -126,3 +170,44 @@ def test_config2_and_config3_full_size():
     assert np.abs(K[idx][:, idx].cpu().numpy() - ref).max() < 1e-12
     del K, psi
     torch.cuda.empty_cache()
+
+
+def test_config3_population_batch_full_size():
+    """configs[2] as the GA runs it: 32 ten-qubit genomes (v5 decoder) x N = 16384 in ONE qk_evaluate_batch call,
+    statistics only (no K copied back).  Two of the genomes are checked against statistics the oracle computes
+    from its own statevectors (K formed block by block on the host, never held whole)."""
+    from quake_amd import genetic
+    from quake_amd.kernels import evaluate_population
+    N, Q, F, G, count = 16384, 10, 18, 8, 32
+    gd = {"single_non_parametric": ["Id", "H", "X", "SX"], "single_parametric": ["RX", "RY", "RZ"],
+          "two_non_parametric": ["CX"], "two_parametric": []}
+    rng = np.random.default_rng(1003)
+    Xall = rng.uniform(1e-6, 1 - 1e-6, size=(N, F))
+    y = rng.integers(0, 2, size=N)
+    pop = genetic.initial_population(count, Q, G, gd, F, rng=rng)
+    cmap = [[q, q + 1] for q in range(Q - 1)] + [[q + 1, q] for q in range(Q - 1)]
+    kw = dict(coupling_map=cmap, variant="v5", physical_qubits=list(range(Q)))
+    decoded = [genetic.to_quantum(g, gd, F, G, Q, verbose=False, **kw) for g in pop]
+    none, stats = evaluate_population([m for m, _ in decoded], [np.ascontiguousarray(Xall[:, xi]) for _, xi in decoded],
+                                      labels=y, return_kernels=False)
+    assert none is None and len(stats) == count
+    for g in (0, count - 1):
+        oops, oxi = O.to_quantum(pop[g], gd, F, G, Q, **kw)
+        psi = O.statevectors(oops, Q, Xall[:, oxi])
+        s = ss = s00 = s11 = s01 = 0.0
+        y0, y1 = (y == 0), (y == 1)
+        B = 2048
+        for r0 in range(0, N, B):
+            Kb = np.abs(psi[r0:r0 + B].conj() @ psi[r0:].T) ** 2          # rows r0.., columns r0.. (upper part)
+            Kb[np.tril_indices(B, 0, Kb.shape[1])] = 0.0                  # strict upper triangle only
+            a0, a1 = y0[r0:r0 + B], y1[r0:r0 + B]
+            c0, c1 = y0[r0:], y1[r0:]
+            s += Kb.sum(); ss += (Kb ** 2).sum()
+            s00 += Kb[a0][:, c0].sum(); s11 += Kb[a1][:, c1].sum()
+            s01 += Kb[a0][:, c1].sum() + Kb[a1][:, c0].sum()
+        n0, n1 = y0.sum(), y1.sum()
+        mean = s / (N * N)
+        want = {"sparsity": (s00 / (n0 * (n0 - 1) / 2) + s11 / (n1 * (n1 - 1) / 2)) / 2 - s01 / (n0 * n1),
+                "offdiagonal_mean": mean, "offdiagonal_std": np.sqrt(ss / (N * N) - mean * mean)}
+        for key, v in want.items():
+            assert abs(stats[g][key] - v) < 1e-10, (g, key, stats[g][key], v)
