@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "qk_common.h"
+#include "qk_wave.h"
 
 namespace qk {
 namespace {
@@ -121,6 +122,63 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         seq.push_back(std::move(p));
     }
     flush();
+
+    // ---- 2b. the wave-resident program (up to 10 qubits: the state lives in one wavefront's registers) ----
+    c.wave_blob.clear();
+    if (n <= kWaveMaxQubits && n_expr <= kWaveMaxExprs) {
+        std::vector<WaveOp> wops;
+        std::vector<WaveTerm> wterms;
+        std::vector<WaveInit> winit(n, WaveInit{-1, -1});
+        std::vector<WaveExpr> wexprs(n_expr);
+        for (int e = 0; e < n_expr; ++e) wexprs[e] = WaveExpr{expr_off[e], expr_off[e + 1] - expr_off[e], 1.0};
+        auto half = [&](int e) { if (e >= 0) wexprs[e].scale = 0.5; };
+        for (const Item& g : inits) {
+            winit[g.q0] = WaveInit{g.gate, g.expr};
+            half(g.expr);
+        }
+        for (const Proto& p : seq) {
+            if (p.diag) {
+                wops.push_back(WaveOp{WV_DIAG, (int32_t)wterms.size(), (int32_t)p.terms.size(), -1});
+                for (const Item& t : p.terms) {
+                    wterms.push_back(WaveTerm{t.kind, t.q0, t.q1 >= 0 ? t.q1 : 0, t.expr});
+                    if (t.kind == TM_RZ) half(t.expr);
+                }
+            } else if (p.nd.kind == ST_U1) {
+                wops.push_back(WaveOp{WV_U1, p.nd.q0, p.nd.gate, p.nd.expr});
+                half(p.nd.expr);
+            } else {
+                wops.push_back(WaveOp{p.nd.kind == ST_CX ? WV_CX : WV_ECR, p.nd.q0, p.nd.q1, -1});
+            }
+        }
+        auto pad8 = [](size_t b) { return (b + 15) / 16 * 16; };   // 16-byte sections: the blob is staged in LDS by 16-byte copies
+        WaveHeader H{};
+        H.n_qubits = n;
+        H.n_params = c.n_params;
+        H.n_ops = (int32_t)wops.size();
+        H.n_terms = (int32_t)wterms.size();
+        H.n_exprs = n_expr;
+        H.n_prog = (int32_t)c.prog.size();
+        H.n_consts = (int32_t)c.consts.size();
+        H.spw = n_expr > 0 ? std::max(1, 64 / n_expr) : 64;
+        size_t off = sizeof(WaveHeader);
+        H.off_ops = (int32_t)off;      off = pad8(off + wops.size() * sizeof(WaveOp));
+        H.off_terms = (int32_t)off;    off = pad8(off + wterms.size() * sizeof(WaveTerm));
+        H.off_init = (int32_t)off;     off = pad8(off + winit.size() * sizeof(WaveInit));
+        H.off_exprs = (int32_t)off;    off = pad8(off + wexprs.size() * sizeof(WaveExpr));
+        H.off_prog = (int32_t)off;     off = pad8(off + c.prog.size() * sizeof(qk_instr));
+        H.off_consts = (int32_t)off;   off = pad8(off + c.consts.size() * sizeof(double));
+        H.bytes = (int32_t)off;
+        c.wave_blob.assign(off / 8, 0);
+        char* base = (char*)c.wave_blob.data();
+        std::memcpy(base, &H, sizeof(H));
+        if (!wops.empty()) std::memcpy(base + H.off_ops, wops.data(), wops.size() * sizeof(WaveOp));
+        if (!wterms.empty()) std::memcpy(base + H.off_terms, wterms.data(), wterms.size() * sizeof(WaveTerm));
+        std::memcpy(base + H.off_init, winit.data(), winit.size() * sizeof(WaveInit));
+        if (!wexprs.empty()) std::memcpy(base + H.off_exprs, wexprs.data(), wexprs.size() * sizeof(WaveExpr));
+        if (!c.prog.empty()) std::memcpy(base + H.off_prog, c.prog.data(), c.prog.size() * sizeof(qk_instr));
+        if (!c.consts.empty()) std::memcpy(base + H.off_consts, c.consts.data(), c.consts.size() * sizeof(double));
+        c.wave_spw = H.spw;
+    }
 
     // ---- 3. passes --------------------------------------------------------
     struct Draft { std::vector<int> S; std::vector<int> stage_ids; int n_term = 0, n_mat = 0; };

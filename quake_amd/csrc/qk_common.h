@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -114,6 +115,21 @@ struct Pass {
 
 }  // namespace qk
 
+namespace qk {
+// One job of the wave-resident simulator (qk_wave.hip): a circuit blob (qk_wave.h), its feature rows and
+// its output.  A unit of work is `spw` consecutive samples of one job; unit_begin = units of the jobs before.
+struct WaveJob {
+    const void* prog;     // device: WaveHeader + tables
+    const double* X;      // device: N x n_params, row stride ldx
+    int64_t ldx;
+    int64_t N;
+    void* psi;            // device: N x 2^n complex128 (f32 == 0) or complex64
+    int64_t unit_begin;
+    int32_t f32;
+    int32_t prog_bytes;   // size of the blob (a multiple of 16)
+};
+}  // namespace qk
+
 struct qk_circuit {
     int n_qubits = 0;
     int n_params = 0;
@@ -126,7 +142,13 @@ struct qk_circuit {
     std::vector<qk::DevMat> mats;
     std::vector<qk_instr> prog;
     std::vector<double> consts;
-    // device copies
+    // wave-resident program (n_qubits <= 10): one position-independent blob, empty when the circuit does not qualify
+    std::vector<uint64_t> wave_blob;
+    int wave_spw = 1;                // samples per unit of work
+    void* d_wave = nullptr;
+    // device copies (uploaded on first use on a device, under `mu`: ctypes releases the GIL, so two host
+    // threads may reach the first call together)
+    std::mutex mu;
     int device = -1;
     qk::DevStage* d_stages = nullptr;
     qk::DevTerm* d_terms = nullptr;
@@ -139,6 +161,11 @@ struct qk_circuit {
 namespace qk {
 // qk_circuit.cpp
 int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr_off, int n_expr);
+// qk_wave.hip
+int wave_nreg_class(int n_qubits);
+size_t wave_lds_bytes(const qk_circuit& c);   // the (cos, sin) table of one unit of work
+int launch_wave_jobs(const WaveJob* jobs_host, int n_jobs, const WaveJob* table_dev, int nreg, int64_t total_units,
+                     size_t cs_bytes, hipStream_t stream);
 // qk_sim.hip
 int upload_circuit(qk_circuit& c);
 void free_circuit_device(qk_circuit& c);

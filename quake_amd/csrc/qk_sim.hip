@@ -14,9 +14,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "qk_common.h"
+#include "qk_math.h"
 #include "qk_rdm.h"
+#include "qk_wave.h"
 
 namespace qk {
 
@@ -214,7 +217,7 @@ __device__ __forceinline__ void run_angle_programs(ExprPtr exprs, ProgPtr prog, 
             }
         }
         double sn, cn;
-        sincos(st[0] * ex.scale, &sn, &cn);
+        sincos_cw(st[0] * ex.scale, &sn, &cn);   // the routine the wave-resident kernel uses: one set of angles per circuit
         if (ex.dst >= 0) {
             rt[ex.dst].c = cn;
             rt[ex.dst].s = sn;
@@ -621,6 +624,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
 int upload_circuit(qk_circuit& c) {
     int dev = 0;
     QK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(c.mu);
     if (c.device == dev) return QK_OK;
     free_circuit_device(c);
     auto up = [&](auto*& dptr, const auto& vec) -> hipError_t {
@@ -637,6 +641,10 @@ int upload_circuit(qk_circuit& c) {
     QK_HIP(up(c.d_mats, c.mats));
     QK_HIP(up(c.d_prog, c.prog));
     QK_HIP(up(c.d_consts, c.consts));
+    if (!c.wave_blob.empty()) {
+        QK_HIP(hipMalloc(&c.d_wave, c.wave_blob.size() * 8));
+        QK_HIP(hipMemcpy(c.d_wave, c.wave_blob.data(), c.wave_blob.size() * 8, hipMemcpyHostToDevice));
+    }
     c.device = dev;
     return QK_OK;
 }
@@ -645,6 +653,8 @@ void free_circuit_device(qk_circuit& c) {
     if (c.device < 0) return;
     (void)hipFree(c.d_stages); (void)hipFree(c.d_terms); (void)hipFree(c.d_exprs);
     (void)hipFree(c.d_mats); (void)hipFree(c.d_prog); (void)hipFree(c.d_consts);
+    if (c.d_wave) (void)hipFree(c.d_wave);
+    c.d_wave = nullptr;
     c.d_stages = nullptr; c.d_terms = nullptr; c.d_exprs = nullptr;
     c.d_mats = nullptr; c.d_prog = nullptr; c.d_consts = nullptr;
     c.device = -1;
@@ -664,6 +674,23 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     int rc = upload_circuit(c);
     if (rc) return rc;
     const int n = c.n_qubits;
+    // up to 10 qubits: the wave-resident kernel (qk_wave.hip) -- the state never leaves the registers of one
+    // wavefront.  QK_SIM_PATH=lds keeps such circuits on the LDS kernel below (A/B runs, and the fused
+    // simulate + RDM mode, which reduces from the LDS image).
+    static const bool force_lds = [] { const char* e = std::getenv("QK_SIM_PATH"); return e && std::strcmp(e, "lds") == 0; }();
+    if (c.d_wave && !rdm_dev && !force_lds) {
+        WaveJob job{};
+        job.prog = c.d_wave;
+        job.X = X_dev;
+        job.ldx = ldx;
+        job.N = N;
+        job.psi = psi32_dev ? psi32_dev : psi_dev;
+        job.f32 = psi32_dev ? 1 : 0;
+        job.unit_begin = 0;
+        job.prog_bytes = (int32_t)(c.wave_blob.size() * 8);
+        const int64_t units = (N + c.wave_spw - 1) / c.wave_spw;
+        return launch_wave_jobs(&job, 1, nullptr, wave_nreg_class(n), units, wave_lds_bytes(c), (hipStream_t)stream);
+    }
     static DeviceOnce attr_set;
     if (attr_set.pending()) {
         QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -1,0 +1,44 @@
+// Program format of the wave-resident simulator (qk_wave.hip): circuits of up to 10 qubits whose whole
+// statevector lives in the registers of ONE wavefront.  Built by the host planner (qk_circuit.cpp) as one
+// position-independent blob, so that a batch of circuits travels to the device in a single copy.
+#pragma once
+#include <cstdint>
+
+namespace qk {
+
+constexpr int kWaveMaxQubits = 10;      // 64 lanes x 16 amplitudes
+constexpr int kWaveMaxExprs = 2048;     // (cos, sin) pairs of one sample in LDS: 32 KiB
+
+enum WaveOpKind : int32_t { WV_U1 = 0, WV_CX = 1, WV_ECR = 2, WV_DIAG = 3 };
+
+struct WaveOp {       // 16 bytes
+    int32_t kind;     // WaveOpKind
+    int32_t a;        // U1: qubit            CX: control   ECR: q0   DIAG: first term
+    int32_t b;        // U1: qk_gate          CX: target    ECR: q1   DIAG: number of terms
+    int32_t c;        // U1: angle index of rx / ry, else -1
+};
+
+struct WaveTerm {     // one factor of a diagonal run
+    int32_t type;     // TermKind
+    int32_t a, b;     // qubits (b unused for TM_P / TM_RZ)
+    int32_t expr;     // angle index, -1 for TM_CZ
+};
+
+struct WaveInit {     // first gate on a qubit, folded into the initial product state
+    int32_t gate;     // qk_gate, or -1: the qubit starts in |0>
+    int32_t expr;     // angle index of rx / ry, else -1
+};
+
+struct WaveExpr {
+    int32_t start, len;   // slice of the postfix program
+    double scale;         // 0.5 for rx / ry / rz (half angle), 1 for p and the ZZ phase
+};
+
+struct WaveHeader {   // 64 bytes, at offset 0 of the blob; off_* are byte offsets from the blob's start
+    int32_t n_qubits, n_params, n_ops, n_terms, n_exprs, n_prog, n_consts;
+    int32_t spw;      // samples whose angles one pass of the wave evaluates together: max(1, 64 / n_exprs)
+    int32_t off_ops, off_terms, off_init, off_exprs, off_prog, off_consts;
+    int32_t bytes, pad;
+};
+
+}  // namespace qk

@@ -93,7 +93,7 @@ def test_fused_simulate_rdm1(n, N, fused):
     want = np.stack([r[..., 0, 0].real, r[..., 1, 1].real, r[..., 0, 1].real, r[..., 0, 1].imag], axis=-1)
     assert np.abs(got - want).max() < 1e-13
     two_step = qdev.rdm1(circ.simulate(Xd), n).cpu().numpy()
-    assert np.abs(got - two_step).max() < 1e-15
+    assert np.abs(got - two_step).max() < 1e-14      # two simulators (LDS-resident fused path, wave-resident kernel): different rounding
 
 
 def test_k_block_to_host_leg():

@@ -20,6 +20,14 @@ def circuits(n):
     extra = {}
     if n >= 9:
         extra = {"ph_low3x4": ph([0, 1, 2]), "ph_mid3x4": ph([3, 4, 5]), "ph_high3x4": ph([n - 4, n - 5, n - 6])}
+    if n <= 12:      # a GA chromosome (v3 decoder, every gate of the alphabet): the config-3 circuit shape
+        from quake_amd import genetic
+        gd = {"single_non_parametric": ["Id", "H", "X", "SX"], "single_parametric": ["RX", "RY", "RZ"],
+              "two_non_parametric": ["CX"], "two_parametric": []}
+        genes = genetic.initial_population(1, n, 8, gd, n, rng=np.random.default_rng(7))[0]
+        g, xi = genetic.to_quantum(genes, gd, n, 8, n, physical_qubits=list(range(n)), verbose=False)
+        if g.num_parameters == n:
+            extra["genome_g8"] = g
     return {"h_only": h, "z_r1": hp, "zz_r1": fm.zz_featuremap(x, n, 1), "zz_r2": fm.zz_featuremap(x, n, 2),
             "custom1_r1": fm.custom1_featuremap(x, n, 1), "custom2_r1": fm.custom2_featuremap(x, n, 1), **extra}
 
