@@ -348,6 +348,206 @@ extern "C" int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t
     return QK_OK;
 }
 
+namespace qk {
+namespace {
+constexpr int64_t kBatchSmallRows = 1024;                 // fused one-block-per-chromosome epilogue up to this many rows
+constexpr size_t kBatchSmallKBytes = (size_t)1 << 30;     // ... and while all kernel matrices together stay under 1 GiB
+constexpr size_t kBatchPsiBytes = (size_t)48 << 30;       // statevectors of one simulate launch
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Chromosomes whose circuit does not run on the wave-resident simulator (more than 10 qubits): one after the
+// other on the null stream, one K buffer reused when the matrix is not asked for.
+int batch_one_by_one(const std::vector<int>& idx, const qk_circuit* const* circuits, const double* const* X, const int64_t* N,
+                     const int32_t* const* labels, int noise, const qk_batch_opts* opts, double* const* K_host, double* stats) {
+    size_t psi_bytes = 0, k_bytes = 0, x_bytes = 0, l_bytes = 0;
+    for (int g : idx) {
+        psi_bytes = std::max(psi_bytes, ((size_t)N[g] << circuits[g]->n_qubits) * 16);
+        k_bytes = std::max(k_bytes, (size_t)N[g] * N[g] * 8);
+        x_bytes = std::max(x_bytes, (size_t)N[g] * circuits[g]->n_params * 8);
+        l_bytes = std::max(l_bytes, (size_t)N[g] * 4);
+    }
+    DevBuf dX, dL, dPsi, dK, dS, dW;
+    QK_HIP(dX.alloc(x_bytes));
+    QK_HIP(dPsi.alloc(psi_bytes));
+    QK_HIP(dK.alloc(k_bytes));
+    if (stats) {
+        QK_HIP(dL.alloc(l_bytes));
+        QK_HIP(dS.alloc(QK_STATS_LEN * sizeof(double)));
+        QK_HIP(dW.alloc((size_t)QK_STATS_WS * sizeof(double)));
+    }
+    for (int g : idx) {
+        const qk_circuit* c = circuits[g];
+        const int64_t n = N[g], D = (int64_t)1 << c->n_qubits;
+        int rc;
+        if (c->n_params) QK_HIP(hipMemcpy(dX.p, X[g], (size_t)n * c->n_params * 8, hipMemcpyHostToDevice));
+        if ((rc = qk_simulate_dev(c, (const double*)dX.p, n, c->n_params, dPsi.p, nullptr))) return rc;
+        if ((rc = qk_gram_dev(dPsi.p, n, nullptr, n, D, (double*)dK.p, n, nullptr))) return rc;
+        if (noise != QK_NOISE_NONE &&
+            (rc = qk_kernel_noise_dev((double*)dK.p, n, n, noise, opts->noise_param, opts->seed + (uint64_t)g, nullptr)))
+            return rc;
+        if (stats) {
+            QK_HIP(hipMemcpy(dL.p, labels[g], (size_t)n * 4, hipMemcpyHostToDevice));
+            if ((rc = qk_kernel_stats_dev((double*)dK.p, n, n, (const int32_t*)dL.p, (double*)dS.p, (double*)dW.p, nullptr))) return rc;
+            QK_HIP(hipMemcpy(stats + (size_t)g * QK_STATS_LEN, dS.p, QK_STATS_LEN * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        if (K_host && K_host[g]) QK_HIP(hipMemcpy(K_host[g], dK.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+    }
+    return QK_OK;
+}
+
+// The heterogeneous batch proper: every chromosome's circuit (a position-independent blob), feature rows, labels and
+// the job tables travel in ONE copy; one simulate launch per register class of the wave-resident kernel walks a job
+// table over all chromosomes; the Gram stage takes 16 chromosomes per launch (qk_gram_jobs_dev).  Small matrices
+// (GA sizes): all of them live at once and one fused launch does noise + statistics for every chromosome.  Large
+// ones: per chromosome, through one reused K buffer.
+int batch_wave(const std::vector<int>& idx, const qk_circuit* const* circuits, const double* const* X, const int64_t* N,
+               const int32_t* const* labels, int noise, const qk_batch_opts* opts, double* const* K_host, double* stats) {
+    const int cnt = (int)idx.size();
+    bool small = true;
+    size_t k_total = 0;
+    for (int g : idx) {
+        small = small && N[g] <= kBatchSmallRows;
+        k_total += (size_t)N[g] * N[g] * 8;
+    }
+    small = small && k_total <= kBatchSmallKBytes;
+    // ---- layout of the staging buffer -------------------------------------------------------------------
+    std::vector<size_t> blob_off(cnt), x_off(cnt), l_off(cnt), psi_off(cnt), k_off(cnt);
+    size_t off = 0, psi_total = 0, k_live = 0, k_max = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const qk_circuit* c = circuits[idx[k]];
+        blob_off[k] = off; off = align_up(off + c->wave_blob.size() * 8, 256);
+    }
+    for (int k = 0; k < cnt; ++k) {
+        const qk_circuit* c = circuits[idx[k]];
+        x_off[k] = off; off = align_up(off + (size_t)N[idx[k]] * c->n_params * 8, 256);
+    }
+    for (int k = 0; k < cnt; ++k) {
+        l_off[k] = off;
+        if (stats) off = align_up(off + (size_t)N[idx[k]] * 4, 256);
+    }
+    const size_t jobs_off = off;     off = align_up(off + (size_t)cnt * sizeof(WaveJob), 256);
+    const size_t epi_off = off;      off = align_up(off + (size_t)cnt * sizeof(EpiJob), 256);
+    const size_t stage_bytes = off;
+    for (int k = 0; k < cnt; ++k) {
+        const qk_circuit* c = circuits[idx[k]];
+        psi_off[k] = psi_total;
+        psi_total += align_up(((size_t)N[idx[k]] << c->n_qubits) * 16, 256);
+        k_off[k] = k_live;
+        k_live += align_up((size_t)N[idx[k]] * N[idx[k]] * 8, 256);
+        k_max = std::max(k_max, (size_t)N[idx[k]] * N[idx[k]] * 8);
+    }
+    if (psi_total > kBatchPsiBytes) return QK_ERR_UNSUPPORTED;   // the caller falls back to one chromosome at a time
+    DevBuf dStage, dPsi, dK, dS, dW;
+    QK_HIP(dStage.alloc(stage_bytes));
+    QK_HIP(dPsi.alloc(psi_total));
+    QK_HIP(dK.alloc(small ? k_live : k_max));
+    QK_HIP(dS.alloc((size_t)cnt * QK_STATS_LEN * sizeof(double)));
+    if (stats && !small) QK_HIP(dW.alloc((size_t)QK_STATS_WS * sizeof(double)));
+    char* base = (char*)dStage.p;
+    // ---- fill: blobs, rows, labels; jobs ordered by register class so that each class is one launch ----------
+    std::vector<char> host(stage_bytes, 0);
+    std::vector<int> order(cnt);
+    for (int k = 0; k < cnt; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return circuits[idx[a]]->n_qubits < circuits[idx[b]]->n_qubits;     // equal qubit counts adjacent: same class, same D
+    });
+    WaveJob* jobs = (WaveJob*)(host.data() + jobs_off);
+    EpiJob* epis = (EpiJob*)(host.data() + epi_off);
+    for (int k = 0; k < cnt; ++k) {
+        const int g = idx[k];
+        const qk_circuit* c = circuits[g];
+        std::memcpy(host.data() + blob_off[k], c->wave_blob.data(), c->wave_blob.size() * 8);
+        if (c->n_params) std::memcpy(host.data() + x_off[k], X[g], (size_t)N[g] * c->n_params * 8);
+        if (stats) std::memcpy(host.data() + l_off[k], labels[g], (size_t)N[g] * 4);
+    }
+    struct ClassRun { int first, count, nreg; int64_t units; size_t cs_bytes; };
+    std::vector<ClassRun> runs;
+    for (int p = 0; p < cnt; ++p) {
+        const int k = order[p], g = idx[k];
+        const qk_circuit* c = circuits[g];
+        const int nreg = wave_nreg_class(c->n_qubits);
+        if (runs.empty() || runs.back().nreg != nreg) runs.push_back(ClassRun{p, 0, nreg, 0, 0});
+        ClassRun& r = runs.back();
+        WaveJob& j = jobs[p];
+        j.prog = base + blob_off[k];
+        j.X = (const double*)(base + x_off[k]);
+        j.ldx = c->n_params;
+        j.N = N[g];
+        j.psi = (char*)dPsi.p + psi_off[k];
+        j.unit_begin = r.units;
+        j.f32 = 0;
+        j.prog_bytes = (int32_t)(c->wave_blob.size() * 8);
+        r.units += (N[g] + c->wave_spw - 1) / c->wave_spw;
+        r.cs_bytes = std::max(r.cs_bytes, wave_lds_bytes(*c));
+        ++r.count;
+        EpiJob& e = epis[k];
+        e.K = (double*)((char*)dK.p + (small ? k_off[k] : 0));
+        e.N = N[g];
+        e.labels = stats ? (const int32_t*)(base + l_off[k]) : nullptr;
+        e.stats = (double*)dS.p + (size_t)k * QK_STATS_LEN;
+        e.seed = (opts ? opts->seed : 0) + (uint64_t)g;
+    }
+    QK_HIP(hipMemcpy(dStage.p, host.data(), stage_bytes, hipMemcpyHostToDevice));
+    // ---- simulate: one launch per register class, every chromosome of the class in it --------------------------
+    int rc;
+    for (const ClassRun& r : runs)
+        if ((rc = launch_wave_jobs(jobs + r.first, r.count, (const WaveJob*)(base + jobs_off) + r.first, r.nreg, r.units,
+                                   r.cs_bytes, nullptr)))
+            return rc;
+    if (small) {
+        // ---- Gram: 16 chromosomes of one dimension per launch -------------------------------------------------
+        for (int p = 0; p < cnt;) {
+            qk_gram_job gj[QK_GRAM_MAX_JOBS];
+            std::memset(gj, 0, sizeof(gj));
+            const int nq = circuits[idx[order[p]]]->n_qubits;
+            int nj = 0;
+            for (; p < cnt && nj < QK_GRAM_MAX_JOBS && circuits[idx[order[p]]]->n_qubits == nq; ++p, ++nj) {
+                const int k = order[p];
+                gj[nj].A = gj[nj].B = (char*)dPsi.p + psi_off[k];
+                gj[nj].K = (double*)((char*)dK.p + k_off[k]);
+                gj[nj].ma = gj[nj].nb = gj[nj].ldk = N[idx[k]];
+                gj[nj].flags = QK_GRAM_SYMMETRIC;
+            }
+            if ((rc = qk_gram_jobs_dev(gj, nj, (int64_t)1 << nq, nullptr))) return rc;
+        }
+        // ---- noise + statistics of every chromosome: one launch -----------------------------------------------
+        if (noise != QK_NOISE_NONE || stats)
+            if ((rc = launch_batch_epilogue((const EpiJob*)(base + epi_off), cnt, noise, opts ? opts->noise_param : 0.0,
+                                            stats != nullptr, nullptr)))
+                return rc;
+        if (K_host)
+            for (int k = 0; k < cnt; ++k)
+                if (K_host[idx[k]])
+                    QK_HIP(hipMemcpy(K_host[idx[k]], (char*)dK.p + k_off[k], (size_t)N[idx[k]] * N[idx[k]] * 8, hipMemcpyDeviceToHost));
+    } else {
+        for (int k = 0; k < cnt; ++k) {
+            const int g = idx[k];
+            const int64_t n = N[g], D = (int64_t)1 << circuits[g]->n_qubits;
+            double* Kg = (double*)dK.p;
+            if ((rc = qk_gram_dev((char*)dPsi.p + psi_off[k], n, nullptr, n, D, Kg, n, nullptr))) return rc;
+            if (noise != QK_NOISE_NONE &&
+                (rc = qk_kernel_noise_dev(Kg, n, n, noise, opts->noise_param, opts->seed + (uint64_t)g, nullptr)))
+                return rc;
+            if (stats && (rc = qk_kernel_stats_dev(Kg, n, n, (const int32_t*)(base + l_off[k]),
+                                                   (double*)dS.p + (size_t)k * QK_STATS_LEN, (double*)dW.p, nullptr)))
+                return rc;
+            // the next chromosome reuses the buffer: a blocking copy (or, with nothing to copy, stream order) keeps it safe
+            if (K_host && K_host[g]) QK_HIP(hipMemcpy(K_host[g], Kg, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    if (stats) {
+        std::vector<double> hs((size_t)cnt * QK_STATS_LEN);
+        QK_HIP(hipMemcpy(hs.data(), dS.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int k = 0; k < cnt; ++k)
+            std::memcpy(stats + (size_t)idx[k] * QK_STATS_LEN, hs.data() + (size_t)k * QK_STATS_LEN, QK_STATS_LEN * sizeof(double));
+    }
+    QK_HIP(hipDeviceSynchronize());
+    return QK_OK;
+}
+}  // namespace
+}  // namespace qk
+
 extern "C" int qk_evaluate_batch(int count, const qk_circuit* const* circuits, const double* const* X, const int64_t* N,
                                  const int32_t* const* labels, const qk_batch_opts* opts, double* const* K_host,
                                  double* stats) {
@@ -355,64 +555,29 @@ extern "C" int qk_evaluate_batch(int count, const qk_circuit* const* circuits, c
     if (count == 0) return QK_OK;
     if (!circuits || !N || (!K_host && !stats)) return fail(QK_ERR_INVALID, "qk_evaluate_batch: null pointer");
     const int noise = opts ? opts->noise_mode : QK_NOISE_NONE;
-    size_t x_elems = 0, k_elems = 0, l_elems = 0, psi_bytes = 0;
-    std::vector<size_t> x_off(count), k_off(count), l_off(count);
+    if (noise != QK_NOISE_NONE && noise != QK_NOISE_GAUSSIAN && noise != QK_NOISE_SHOTS)
+        return fail(QK_ERR_INVALID, "qk_evaluate_batch: unknown noise mode");
+    if (noise == QK_NOISE_GAUSSIAN && !(opts->noise_param >= 0.0))
+        return fail(QK_ERR_INVALID, "qk_evaluate_batch: negative standard deviation");
+    if (noise == QK_NOISE_SHOTS && (!(opts->noise_param >= 1.0) || opts->noise_param > 1e9))
+        return fail(QK_ERR_INVALID, "qk_evaluate_batch: shots must be in 1..1e9");
+    std::vector<int> wave, other;
     for (int g = 0; g < count; ++g) {
         const qk_circuit* c = circuits[g];
         if (!c) return fail(QK_ERR_INVALID, "qk_evaluate_batch: null circuit");
         if (N[g] < 1) return fail(QK_ERR_INVALID, "qk_evaluate_batch: every genome needs at least one row");
         if (c->n_params > 0 && (!X || !X[g])) return fail(QK_ERR_INVALID, "qk_evaluate_batch: X is null");
         if (stats && (!labels || !labels[g])) return fail(QK_ERR_INVALID, "qk_evaluate_batch: statistics need labels");
-        x_off[g] = x_elems;
-        k_off[g] = k_elems;
-        l_off[g] = l_elems;
-        x_elems += (size_t)N[g] * c->n_params;
-        k_elems += (size_t)N[g] * N[g];
-        l_elems += (size_t)N[g];
-        psi_bytes = std::max(psi_bytes, ((size_t)N[g] << c->n_qubits) * 16);
+        (c->wave_blob.empty() ? other : wave).push_back(g);
     }
     int rc = check_device();
     if (rc) return rc;
-    // one staging copy each for all feature rows and all labels
-    std::vector<double> hx(x_elems);
-    std::vector<int32_t> hl(stats ? l_elems : 0);
-    for (int g = 0; g < count; ++g) {
-        const size_t nx = (size_t)N[g] * circuits[g]->n_params;
-        if (nx) std::memcpy(hx.data() + x_off[g], X[g], nx * sizeof(double));
-        if (stats) std::memcpy(hl.data() + l_off[g], labels[g], (size_t)N[g] * sizeof(int32_t));
+    if (!wave.empty()) {
+        rc = batch_wave(wave, circuits, X, N, labels, noise, opts, K_host, stats);
+        if (rc == QK_ERR_UNSUPPORTED) rc = batch_one_by_one(wave, circuits, X, N, labels, noise, opts, K_host, stats);
+        if (rc) return rc;
     }
-    DevBuf dX, dL, dPsi, dK, dS, dW;
-    QK_HIP(dX.alloc(x_elems * sizeof(double)));
-    if (x_elems) QK_HIP(hipMemcpy(dX.p, hx.data(), x_elems * sizeof(double), hipMemcpyHostToDevice));
-    if (stats) {
-        QK_HIP(dL.alloc(l_elems * sizeof(int32_t)));
-        QK_HIP(hipMemcpy(dL.p, hl.data(), l_elems * sizeof(int32_t), hipMemcpyHostToDevice));
-        QK_HIP(dS.alloc((size_t)count * QK_STATS_LEN * sizeof(double)));
-        QK_HIP(dW.alloc((size_t)QK_STATS_WS * sizeof(double)));
-    }
-    QK_HIP(dPsi.alloc(psi_bytes));
-    QK_HIP(dK.alloc(k_elems * sizeof(double)));
-    // everything below is enqueued on the null stream in order: Psi and the statistics workspace
-    // are reused from genome to genome without a host synchronisation in between
-    for (int g = 0; g < count; ++g) {
-        const qk_circuit* c = circuits[g];
-        const int64_t n = N[g], D = (int64_t)1 << c->n_qubits;
-        double* Kg = (double*)dK.p + k_off[g];
-        if ((rc = qk_simulate_dev(c, (const double*)dX.p + x_off[g], n, c->n_params, dPsi.p, nullptr))) return rc;
-        if ((rc = qk_gram_dev(dPsi.p, n, nullptr, n, D, Kg, n, nullptr))) return rc;
-        if (noise != QK_NOISE_NONE &&
-            (rc = qk_kernel_noise_dev(Kg, n, n, noise, opts->noise_param, opts->seed + (uint64_t)g, nullptr)))
-            return rc;
-        if (stats && (rc = qk_kernel_stats_dev(Kg, n, n, (const int32_t*)dL.p + l_off[g],
-                                               (double*)dS.p + (size_t)g * QK_STATS_LEN, (double*)dW.p, nullptr)))
-            return rc;
-    }
-    if (K_host)
-        for (int g = 0; g < count; ++g)
-            if (K_host[g])
-                QK_HIP(hipMemcpy(K_host[g], (double*)dK.p + k_off[g], (size_t)N[g] * N[g] * sizeof(double),
-                                 hipMemcpyDeviceToHost));
-    if (stats) QK_HIP(hipMemcpy(stats, dS.p, (size_t)count * QK_STATS_LEN * sizeof(double), hipMemcpyDeviceToHost));
+    if (!other.empty() && (rc = batch_one_by_one(other, circuits, X, N, labels, noise, opts, K_host, stats))) return rc;
     QK_HIP(hipDeviceSynchronize());
     return QK_OK;
 }

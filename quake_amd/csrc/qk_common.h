@@ -161,6 +161,16 @@ struct qk_circuit {
 namespace qk {
 // qk_circuit.cpp
 int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr_off, int n_expr);
+// qk_stats.hip: noise + statistics of many small symmetric matrices in one launch (dense, ldk = N)
+struct EpiJob {
+    double* K;
+    int64_t N;
+    const int32_t* labels;   // may be null when no statistics are asked for
+    double* stats;           // QK_STATS_LEN doubles
+    uint64_t seed;
+};
+int launch_batch_epilogue(const EpiJob* table_dev, int count, int noise_mode, double noise_param, bool want_stats,
+                          hipStream_t stream);
 // qk_wave.hip
 int wave_nreg_class(int n_qubits);
 size_t wave_lds_bytes(const qk_circuit& c);   // the (cos, sin) table of one unit of work

@@ -102,41 +102,102 @@ __device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint
     return U4{c0, c1, c2, c3};
 }
 
-__global__ void __launch_bounds__(256) noise_kernel(double* __restrict__ K, int64_t N, int64_t ldk, int mode, double param,
-                                                    uint32_t k0, uint32_t k1) {
-    // 16 x 16 thread tiles over the upper triangle; (i, j) with i < j
-    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
-    const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (i >= N || j >= N || i >= j) return;
-    const double v = K[i * ldk + j];
-    double out;
+// one noisy entry: Gaussian noise + clip, or a binomial estimate from `param` shots; counter = (i, j, t, 0)
+__device__ __forceinline__ double noisy_value(double v, int64_t i, int64_t j, int mode, double param, uint32_t k0, uint32_t k1) {
     if (mode == QK_NOISE_GAUSSIAN) {
         const U4 r = philox((uint32_t)i, (uint32_t)j, 0u, 0u, k0, k1);
         // two 53-bit uniforms in (0, 1]
         const double u1 = ((double)(((uint64_t)r.x << 21) ^ (r.y >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
         const double u2 = ((double)(((uint64_t)r.z << 21) ^ (r.w >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
         const double g = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
-        out = fmin(fmax(v + param * g, 0.0), 1.0);
-    } else {
-        const int64_t shots = (int64_t)param;
-        const double p = fmin(fmax(v, 0.0), 1.0);
-        const uint64_t thr = (uint64_t)(p * 4294967296.0);       // P(u32 < thr) = p to 2^-32
-        int64_t hits = 0;
-        for (int64_t t = 0; t * 4 < shots; ++t) {
-            const U4 r = philox((uint32_t)i, (uint32_t)j, (uint32_t)t, (uint32_t)(t >> 32), k0, k1);
-            const int64_t left = shots - t * 4;
-            hits += (uint64_t)r.x < thr;
-            if (left > 1) hits += (uint64_t)r.y < thr;
-            if (left > 2) hits += (uint64_t)r.z < thr;
-            if (left > 3) hits += (uint64_t)r.w < thr;
-        }
-        out = (double)hits / (double)shots;
+        return fmin(fmax(v + param * g, 0.0), 1.0);
     }
+    const int64_t shots = (int64_t)param;
+    const double p = fmin(fmax(v, 0.0), 1.0);
+    const uint64_t thr = (uint64_t)(p * 4294967296.0);       // P(u32 < thr) = p to 2^-32
+    int64_t hits = 0;
+    for (int64_t t = 0; t * 4 < shots; ++t) {
+        const U4 r = philox((uint32_t)i, (uint32_t)j, (uint32_t)t, (uint32_t)(t >> 32), k0, k1);
+        const int64_t left = shots - t * 4;
+        hits += (uint64_t)r.x < thr;
+        if (left > 1) hits += (uint64_t)r.y < thr;
+        if (left > 2) hits += (uint64_t)r.z < thr;
+        if (left > 3) hits += (uint64_t)r.w < thr;
+    }
+    return (double)hits / (double)shots;
+}
+
+__global__ void __launch_bounds__(256) noise_kernel(double* __restrict__ K, int64_t N, int64_t ldk, int mode, double param,
+                                                    uint32_t k0, uint32_t k1) {
+    // 16 x 16 thread tiles over the upper triangle; (i, j) with i < j
+    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= N || j >= N || i >= j) return;
+    const double out = noisy_value(K[i * ldk + j], i, j, mode, param, k0, k1);
     K[i * ldk + j] = out;
     K[j * ldk + i] = out;
 }
 
+// One GA generation's epilogue in ONE launch: block g owns chromosome g's (small) kernel matrix -- noise on the
+// upper triangle (mirrored), then the statistics of the noisy matrix, reduced inside the block in a fixed order.
+__global__ void __launch_bounds__(kStatThreads) batch_epilogue_kernel(const EpiJob* __restrict__ jobs, int mode, double param,
+                                                                      int want_stats) {
+    __shared__ double sh[5 * kStatThreads];
+    const EpiJob J = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int64_t N = J.N;
+    const uint32_t k0 = (uint32_t)J.seed, k1 = (uint32_t)(J.seed >> 32);
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < N; ++i) {
+        const int li = (want_stats && J.labels) ? J.labels[i] : -1;
+        double* row = J.K + i * N;
+        for (int64_t j = i + 1 + tid; j < N; j += kStatThreads) {
+            double v = row[j];
+            if (mode != QK_NOISE_NONE) {
+                v = noisy_value(v, i, j, mode, param, k0, k1);
+                row[j] = v;
+                J.K[j * N + i] = v;
+            }
+            if (want_stats) {
+                acc[0] += v;
+                acc[1] = fma(v, v, acc[1]);
+                const int lj = J.labels[j];
+                if (li == 0 && lj == 0) acc[2] += v;
+                else if (li == 1 && lj == 1) acc[3] += v;
+                else if ((li == 0 && lj == 1) || (li == 1 && lj == 0)) acc[4] += v;
+            }
+        }
+    }
+    if (!want_stats) return;
+    block_reduce5(acc, sh, tid);
+    __syncthreads();
+    double cnt[5] = {0, 0, 0, 0, 0};
+    for (int64_t i = tid; i < N; i += kStatThreads) {
+        cnt[0] += J.labels[i] == 0;
+        cnt[1] += J.labels[i] == 1;
+    }
+    block_reduce5(cnt, sh, tid);
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) J.stats[k] = acc[k];
+        J.stats[5] = cnt[0];
+        J.stats[6] = cnt[1];
+        J.stats[7] = 0.0;
+    }
+}
+
 }  // namespace
+}  // namespace qk
+
+namespace qk {
+int launch_batch_epilogue(const EpiJob* table_dev, int count, int noise_mode, double noise_param, bool want_stats,
+                          hipStream_t stream) {
+    if (count < 1) return QK_OK;
+    hipLaunchKernelGGL(batch_epilogue_kernel, dim3((unsigned)count), dim3(kStatThreads), 0, stream, table_dev, noise_mode,
+                       noise_param, want_stats ? 1 : 0);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
 }  // namespace qk
 
 using namespace qk;
