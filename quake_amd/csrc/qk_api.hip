@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -179,6 +180,21 @@ extern "C" int qk_simulate(const qk_circuit* c, const double* X, int64_t N, int6
 
 namespace qk {
 namespace {
+// side streams of the host entry points, one pair per device, created on first use and kept
+int side_streams(hipStream_t* compute, hipStream_t* copy) {
+    static std::mutex mu;
+    static hipStream_t streams[64][2] = {};
+    int dev = 0;
+    QK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(QK_ERR_UNSUPPORTED, "device index out of range");
+    std::lock_guard<std::mutex> lock(mu);
+    for (int k = 0; k < 2; ++k)
+        if (!streams[dev][k]) QK_HIP(hipStreamCreateWithFlags(&streams[dev][k], hipStreamNonBlocking));
+    *compute = streams[dev][0];
+    *copy = streams[dev][1];
+    return QK_OK;
+}
+
 // The Gram stage of the host entry points, with the copy of K back to the host hidden behind it.
 // K is produced in row bands (each band = one multi-job launch: its diagonal block as a symmetric job,
 // the block to its right as a cross job whose transposed copy fills the mirror entries of the later
@@ -207,21 +223,27 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
         QK_HIP(hipMemcpy(K_host, K, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));
         return QK_OK;
     }
+    // two side streams per device, created once and kept (a host application's own streams are left alone: no
+    // device-wide synchronisation here)
     hipStream_t compute = nullptr, copy = nullptr;
+    int rc = side_streams(&compute, &copy);
+    if (rc) return rc;
     std::vector<hipEvent_t> done;
-    int rc = QK_OK;
     auto cleanup = [&]() {
         for (hipEvent_t e : done) (void)hipEventDestroy(e);
-        if (compute) (void)hipStreamDestroy(compute);
-        if (copy) (void)hipStreamDestroy(copy);
     };
-    if (hipStreamCreateWithFlags(&compute, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) {
-        cleanup();
-        return fail(QK_ERR_HIP, "gram_to_host: cannot create streams");
-    }
     // the simulations ran on the null stream: order the compute stream behind them
-    if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return fail(QK_ERR_HIP, "gram_to_host: device synchronisation failed"); }
+    {
+        hipEvent_t sim_done;
+        if (hipEventCreateWithFlags(&sim_done, hipEventDisableTiming) != hipSuccess)
+            return fail(QK_ERR_HIP, "gram_to_host: cannot create event");
+        done.push_back(sim_done);
+        if (hipEventRecord(sim_done, nullptr) != hipSuccess || hipStreamWaitEvent(compute, sim_done, 0) != hipSuccess) {
+            cleanup();
+            return fail(QK_ERR_HIP, "gram_to_host: cannot order the compute stream behind the simulation");
+        }
+    }
+    const size_t first_band_event = done.size();
     for (int64_t r0 = 0; r0 < N && rc == QK_OK; r0 += band) {
         const int64_t r1 = std::min(N, r0 + band);
         qk_gram_job jobs[2];
@@ -244,15 +266,17 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
             ++nj;
         }
         rc = launch(jobs, nj, D, compute);
+        if (rc != QK_OK) break;
         hipEvent_t e;
-        if (rc == QK_OK && (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess ||
-                            hipEventRecord(e, compute) != hipSuccess))
-            rc = fail(QK_ERR_HIP, "gram_to_host: cannot record event");
-        else if (rc == QK_OK)
-            done.push_back(e);
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            rc = fail(QK_ERR_HIP, "gram_to_host: cannot create event");
+            break;
+        }
+        done.push_back(e);      // owned by `done` from here on, whatever happens to the record
+        if (hipEventRecord(e, compute) != hipSuccess) rc = fail(QK_ERR_HIP, "gram_to_host: cannot record event");
     }
     // every launch is queued; now drain band by band while the later bands compute
-    size_t b = 0;
+    size_t b = first_band_event;
     for (int64_t r0 = 0; r0 < N && rc == QK_OK; r0 += band, ++b) {
         const int64_t r1 = std::min(N, r0 + band);
         if (hipStreamWaitEvent(copy, done[b], 0) != hipSuccess ||
@@ -261,7 +285,9 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
             hipStreamSynchronize(copy) != hipSuccess)
             rc = fail(QK_ERR_HIP, "gram_to_host: copy of K failed");
     }
-    if (hipDeviceSynchronize() != hipSuccess && rc == QK_OK) rc = fail(QK_ERR_HIP, "gram_to_host: device synchronisation failed");
+    // on an error path kernels may still be running on the buffers the caller is about to free
+    if (hipStreamSynchronize(compute) != hipSuccess && rc == QK_OK) rc = fail(QK_ERR_HIP, "gram_to_host: synchronisation failed");
+    if (hipStreamSynchronize(copy) != hipSuccess && rc == QK_OK) rc = fail(QK_ERR_HIP, "gram_to_host: synchronisation failed");
     cleanup();
     return rc;
 }

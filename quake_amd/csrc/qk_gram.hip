@@ -12,13 +12,17 @@
 //       VALU add per fragment).  Same result to ~1e-16; 25 % fewer matrix-core cycles.
 // The algorithmic count stays 8 real flops per amplitude and entry.
 //
-// A and B tiles are staged global -> registers -> LDS, double buffered, one barrier
-// per BK amplitudes.  LDS images are k-major ([amplitude][row], 16-B elements, one
-// element of padding per k row) so fragment reads are conflict free.
+// The shipped kernel (gram_dma_kernel, 64 x 64 block tiles, four waves, two workgroups per CU): A and B tiles
+// go HBM/L2 -> LDS directly with global_load_lds (no staging registers), double buffered, one barrier per 16
+// amplitudes.  The LDS image is row-major with 256-byte rows; the DMA writes linearly, so the bank swizzle sits
+// on the SOURCE address (slot s of row r holds amplitude s ^ (r & 15)) and the b128 fragment reads are conflict
+// free.  The register-staged kernel below it (gram_kernel, k-major LDS image with one element of padding per
+// row) serves circuits under 4 qubits, where a 16-amplitude k-tile does not exist, and A/B runs.
 //
-// Tile schedule: macro-tiles of 4 x 8 block tiles dealt round-robin to the 8 XCD labels
-// (block id % 8), so the 32 workgroups that share an L2 at any time share A rows (8x)
-// and B rows (4x); symmetric jobs list only macro-tiles that reach the diagonal.
+// Tile schedule (gram_locate): the tiles that have to be computed are listed band by band (8 tile rows),
+// column-major inside a band, and cut into groups of 64 consecutive tiles -- an 8 x 8 macro-tile without dead
+// tiles -- dealt round-robin to the 8 XCD labels (block id % 8): the 64 workgroups resident on an XCD share 8 A
+// and 8 B row blocks in its L2; symmetric jobs list only tiles on or above the diagonal.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -808,18 +812,18 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // ahead there).  N = 4096, n = 8: +34 % over 128 x 128.
 constexpr int kDefaultVariant = 5;   // dma3m_64x64_w4_g64
 
-static int g_variant = -1;       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = the default
-static bool g_env_read = false;
+static std::atomic<int> g_variant{-1};       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = the default
+static std::atomic<bool> g_env_read{false};
 static DeviceOnce g_attr_set[kNumVariants];
 
 static int pick_variant(const qk_gram_job* jobs, int n_jobs, int64_t D) {
-    if (!g_env_read) {
-        g_env_read = true;
+    if (!g_env_read.exchange(true)) {
         if (const char* e = std::getenv("QK_GRAM_VARIANT"))
             for (int v = 0; v < kNumVariants; ++v)
                 if (std::strcmp(e, kVariants[v].name) == 0) g_variant = v;
     }
-    if (g_variant >= 0) return g_variant;
+    const int forced = g_variant.load();
+    if (forced >= 0) return forced;
     (void)jobs; (void)n_jobs; (void)D;
     return kDefaultVariant;
 }
@@ -945,7 +949,7 @@ static int launch_gram32(const qk_gram_job* jobs, int n_jobs, int64_t D, hipStre
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
-static int g_tile32 = 0;   // 0 = choose per call, 64 / 128 = forced (QK_GRAM32_TILE, A/B runs)
+static std::atomic<int> g_tile32{0};   // 0 = choose per call, 64 / 128 = forced (QK_GRAM32_TILE, A/B runs)
 }  // namespace qk
 
 extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
@@ -968,12 +972,11 @@ extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D
         QK_HIP(hipGetLastError());
         return QK_OK;
     }
-    static bool env_read = false;
-    if (!env_read) {
-        env_read = true;
+    static std::atomic<bool> env_read{false};
+    if (!env_read.exchange(true)) {
         if (const char* e = std::getenv("QK_GRAM32_TILE")) g_tile32 = std::atoi(e);
     }
-    const bool big = g_tile32 == 128;   // 64 x 64 tiles measured faster at every size (168 vs 166 TFLOP/s at N = 65536, n = 16)
+    const bool big = g_tile32.load() == 128;   // 64 x 64 tiles measured faster at every size (168 vs 166 TFLOP/s at N = 65536, n = 16)
     return big ? launch_gram32<2, 4, 4, 2>(jobs, n_jobs, D, (hipStream_t)stream)
                : launch_gram32<2, 2, 2, 2>(jobs, n_jobs, D, (hipStream_t)stream);
 }

@@ -117,7 +117,7 @@ __device__ __forceinline__ double exp_poly(double x, const double (&c)[12]) {
 __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx, int64_t N,
                                                    const double* __restrict__ ry, int64_t M, int n, double gamma,
                                                    double* __restrict__ K, int64_t ldk, int sym, int tiles_n) {
-    extern __shared__ double sh[];  // x side then y side, each [n][4][PTP]
+    extern __shared__ double sh[];  // x side then y side, each [n][3][PTP]
     int ti, tj;
     if (sym) {  // upper-triangular tile list: blockIdx -> (ti, tj >= ti); T(r) = r * tiles_n - r (r - 1) / 2 tiles precede row r
         const int b = blockIdx.x;
@@ -133,9 +133,10 @@ __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx,
         ti = blockIdx.x / tiles_n;
         tj = blockIdx.x % tiles_n;
     }
-    const int w = n * 4;
+    const int w = n * 4;          // doubles per row of the RDM table (rho00, rho11, Re rho01, Im rho01 per qubit)
+    const int w3 = n * 3;         // ... of the LDS image: rho11 = 1 - rho00 carries nothing the norm does not already have
     double* sx = sh;
-    double* sy = sh + PTP * w;
+    double* sy = sh + PTP * w3;
     const int tid = threadIdx.x;
     {
         // The tile's 64 RDM rows are one contiguous run of 64 * w doubles: read it linearly (coalesced)
@@ -147,11 +148,14 @@ __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx,
         int r = tid / w, c = tid - r * w;
         const int dr = 256 / w, dc = 256 - dr * w;
         for (int e = tid; e < total; e += 256) {
-            // components 2, 3 (Re, Im of rho01) are stored times sqrt(2): |d00|^2 + |d11|^2 + 2 |d01|^2
-            // becomes a plain sum of four squares
-            const double sc = (c & 2) ? 1.4142135623730951 : 1.0;
-            sx[c * PTP + r] = e < xl ? sc * rx[xbase + e] : 0.0;
-            sy[c * PTP + r] = e < yl ? sc * ry[ybase + e] : 0.0;
+            // ||d rho||_F^2 = d00^2 + d11^2 + 2 |d01|^2 = 2 (d00^2 + Re d01^2 + Im d01^2) since d11 = -d00 (unit trace):
+            // the three kept components are stored times sqrt(2) and the norm is a plain sum of three squares
+            const int comp = c & 3;
+            if (comp != 1) {
+                const int slot = (c >> 2) * 3 + (comp ? comp - 1 : 0);
+                sx[slot * PTP + r] = e < xl ? 1.4142135623730951 * rx[xbase + e] : 0.0;
+                sy[slot * PTP + r] = e < yl ? 1.4142135623730951 * ry[ybase + e] : 0.0;
+            }
             r += dr;
             c += dc;
             if (c >= w) { c -= w; ++r; }
@@ -165,22 +169,20 @@ __global__ void __launch_bounds__(256) pqk_kernel(const double* __restrict__ rx,
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
     for (int q = 0; q < n; ++q) {
-        double a[4][4], b[4][4];
+        double a[4][3], b[4][3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                a[r][k] = sx[(q * 4 + k) * PTP + ty + 16 * r];
-                b[r][k] = sy[(q * 4 + k) * PTP + tx + 16 * r];
+                a[r][k] = sx[(q * 3 + k) * PTP + ty + 16 * r];
+                b[r][k] = sy[(q * 3 + k) * PTP + tx + 16 * r];
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const double d0 = a[r][0] - b[c][0], d1 = a[r][1] - b[c][1];
-                const double dr = a[r][2] - b[c][2], di = a[r][3] - b[c][3];
-                // Frobenius norm of the 2x2 difference: |d00|^2 + |d11|^2 + 2 |d01|^2
-                acc[r][c] = add_twice_sqrt(acc[r][c], fma(d0, d0, fma(d1, d1, fma(dr, dr, fma(di, di, 1e-300)))));
+                const double d0 = a[r][0] - b[c][0], dr = a[r][1] - b[c][1], di = a[r][2] - b[c][2];
+                acc[r][c] = add_twice_sqrt(acc[r][c], fma(d0, d0, fma(dr, dr, fma(di, di, 1e-300))));
             }
     }
     // exponentials first, branch-free over the whole 4 x 4 block (so the polynomial's constants are
@@ -260,7 +262,7 @@ extern "C" int qk_pqk_dev(const double* rdm_x, int64_t N, const double* rdm_y, i
     const int64_t tm = (N + PT - 1) / PT, tn = (M + PT - 1) / PT;
     const int64_t nblocks = sym ? tn * (tn + 1) / 2 : tm * tn;
     if (nblocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, "qk_pqk_dev: too many tiles");
-    const size_t lds = (size_t)2 * PTP * n_qubits * 4 * sizeof(double);
+    const size_t lds = (size_t)2 * PTP * n_qubits * 3 * sizeof(double);
     if (lds > 64 * 1024) {
         static DeviceOnce attr_set;
         if (attr_set.pending()) {

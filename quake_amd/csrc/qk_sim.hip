@@ -104,56 +104,51 @@ __device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, con
                                          uint32_t nloc, int tid, int T) {
     // NG single-qubit gates on distinct local qubits in one sweep: each thread holds the 2^NG
     // amplitudes that differ in the target bits and applies the gates in registers.
-    // form: 0 = real matrix (h, x, ry), 1 = real diagonal + imaginary off-diagonal (rx), 2 = general (sx)
+    // form: 0 = real matrix (x, ry), 1 = real diagonal + imaginary off-diagonal (rx), 2 = general (sx),
+    //       3 = hadamard (adds only; the factors 1/sqrt 2 of the group are applied once at the end)
+    // The 2^NG amplitude offsets depend on the stage only (wave-uniform: scalar registers), so an item costs
+    // NG bit insertions and one OR per amplitude.  (An XOR-swizzled register mapping that removed the LDS bank
+    // conflicts of low target bits made the offsets per-lane values and bought no time: the sweeps are bound
+    // by VALU issue, not by LDS.)
     double2 m[NG][4];
-    uint32_t lm[NG];
+    uint32_t lm[NG], off[1 << NG];
     int form[NG];
-    // Target bits below 4 make consecutive lanes walk LDS with a 2^t-amplitude stride (2^t-way bank
-    // conflicts on the 16-byte accesses).  Remedy: lane l reads register k from the amplitude whose
-    // low target bits are k ^ X(l), X taken from the lane bits that would otherwise only select the
-    // 256-byte row -- 16 consecutive lanes then cover all 16 slots of a row.  Registers k and k ^ m
-    // still hold a pair that differs in target bit m; where X has that bit set the pair is held
-    // in swapped order, which is the same as applying the gate with its rows and columns swapped.
-    int t_low = 0;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) t_low += st.gv[g] < 4 ? 1 : 0;
-    uint32_t X = 0;
-    if ((nloc >> NG) >= 16u) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-            if (g < t_low) X |= (((uint32_t)tid >> (4 - t_low + g)) & 1u) << g;
-    }
+    double hscale = 1.0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[g][k] = mat[4 * st.gm[g] + k];
-        if ((X >> g) & 1u) {
-            double2 t0 = m[g][0], t1 = m[g][1];
-            m[g][0] = m[g][3]; m[g][3] = t0;
-            m[g][1] = m[g][2]; m[g][2] = t1;
-        }
         lm[g] = (1u << st.gv[g]) - 1u;
         const int gate = mats[st.gm[g]].gate;
-        form[g] = (gate == QK_H || gate == QK_X || gate == QK_RY) ? 0 : (gate == QK_RX ? 1 : 2);
+        form[g] = gate == QK_H ? 3 : ((gate == QK_X || gate == QK_RY) ? 0 : (gate == QK_RX ? 1 : 2));
+        if (gate == QK_H) hscale *= 0.70710678118654752440;
     }
-    for (uint32_t i = tid; i < (nloc >> NG); i += T) {
+#pragma unroll
+    for (int k = 0; k < (1 << NG); ++k) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) o |= (((uint32_t)k >> g) & 1u) << st.gv[g];
+        off[k] = o;
+    }
+    auto base_of = [&](uint32_t i) {
         uint32_t b = i;
 #pragma unroll
         for (int g = 0; g < NG; ++g) b = ((b & ~lm[g]) << 1) | (b & lm[g]);   // target bits ascending
-        double2 v[1 << NG];
-        uint32_t idx[1 << NG];
-#pragma unroll
-        for (int k = 0; k < (1 << NG); ++k) {
-            const uint32_t kx = (uint32_t)k ^ X;
-            uint32_t o = b;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) o |= ((kx >> g) & 1u) << st.gv[g];
-            idx[k] = o;
-            v[k] = state[o];
-        }
+        return b;
+    };
+    auto butterflies = [&](double2 (&v)[1 << NG]) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (form[g] == 0) {
+            if (form[g] == 3) {
+#pragma unroll
+                for (int k = 0; k < (1 << NG); ++k)
+                    if (!((k >> g) & 1)) {
+                        const int k1 = k | (1 << g);
+                        const double2 a0 = v[k], a1 = v[k1];
+                        v[k] = make_double2(a0.x + a1.x, a0.y + a1.y);
+                        v[k1] = make_double2(a0.x - a1.x, a0.y - a1.y);
+                    }
+            } else if (form[g] == 0) {
 #pragma unroll
                 for (int k = 0; k < (1 << NG); ++k)
                     if (!((k >> g) & 1)) {
@@ -183,8 +178,23 @@ __device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, con
                     }
             }
         }
+        if (hscale != 1.0) {
 #pragma unroll
-        for (int k = 0; k < (1 << NG); ++k) state[idx[k]] = v[k];
+            for (int k = 0; k < (1 << NG); ++k) v[k] = make_double2(v[k].x * hscale, v[k].y * hscale);
+        }
+    };
+    const uint32_t items = nloc >> NG;
+    uint32_t i = tid;
+    // (Two items per trip, the second one's LDS reads in flight while the first is computed, was tried: the extra
+    // 64 registers spill in the radix-8 kernel and the sweep gets slower, 6.8 -> 7.9 ms on ZZ r = 2 at 16 qubits.)
+    for (; i < items; i += T) {
+        const uint32_t b = base_of(i);
+        double2 v[1 << NG];
+#pragma unroll
+        for (int k = 0; k < (1 << NG); ++k) v[k] = state[b | off[k]];
+        butterflies(v);
+#pragma unroll
+        for (int k = 0; k < (1 << NG); ++k) state[b | off[k]] = v[k];
     }
 }
 

@@ -23,6 +23,26 @@ def _dp(t: Optional[torch.Tensor]) -> Optional[C.c_void_p]:
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def from_dlpack(x) -> Optional[torch.Tensor]:
+    """DLPack hand-off at the device boundary (BASELINE.json north_star: "DLPack/numpy hand-off"): anything that
+    implements ``__dlpack__`` (a cupy / jax / numba array, another framework's tensor) or a raw DLPack capsule is
+    viewed -- zero copy -- as the torch tensor the launchers work on; torch tensors pass through.  Every tensor
+    this module returns implements ``__dlpack__`` itself, so results travel back the same way
+    (``consumer.from_dlpack(K)``)."""
+    if x is None or isinstance(x, torch.Tensor):
+        return x
+    if hasattr(x, "__dlpack__"):
+        return torch.from_dlpack(x)
+    if type(x).__name__ == "PyCapsule":
+        return torch.utils.dlpack.from_dlpack(x)
+    raise TypeError(f"expected a torch tensor, an object with __dlpack__ or a DLPack capsule, got {type(x).__name__}")
+
+
+def to_dlpack(t: torch.Tensor):
+    """A DLPack capsule of a result tensor (for consumers that take capsules rather than ``__dlpack__`` objects)."""
+    return torch.utils.dlpack.to_dlpack(t)
+
+
 def _require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -43,6 +63,7 @@ class DeviceCircuit:
     def simulate(self, X: torch.Tensor, out: Optional[torch.Tensor] = None, dtype=torch.complex128) -> torch.Tensor:
         """X float64 [N, n_params] (row stride free) -> Psi [N, 2^n], complex128 or (FP32 mode:
         evolved in FP64, rounded at the store) complex64 -- the dtype of ``out`` if given."""
+        X, out = from_dlpack(X), from_dlpack(out)
         _require_gpu(X, out)
         if X.dtype != torch.float64 or X.dim() != 2 or X.stride(1) != 1:
             raise ValueError("X must be a float64 [N, F] tensor with unit column stride")
@@ -71,6 +92,7 @@ class DeviceCircuit:
 def simulate_rdm1(circuit: "DeviceCircuit", X: torch.Tensor) -> torch.Tensor:
     """Per-qubit reduced density matrices of the encoded states, float64 [N, n, 4], without writing
     the statevectors when the circuit fits one LDS-resident pass (``qk_simulate_rdm1_dev``)."""
+    X = from_dlpack(X)
     _require_gpu(X)
     lib = _lib.load()
     if X.dtype != torch.float64 or X.dim() != 2 or X.shape[1] != circuit.n_params or (X.numel() and X.stride(1) != 1):
@@ -90,6 +112,8 @@ def gram_jobs(jobs: Sequence[dict], D: int) -> None:
     """Run several block jobs in one launch.  Each job: dict(A=, B=, K=, KT=None, symmetric=False);
     A, B complex128 (or, for the FP32 Gram stage, complex64) [rows, D] contiguous; K (and KT) float64
     2-D views with unit column stride."""
+    jobs = [dict(j, A=from_dlpack(j["A"]), B=from_dlpack(j["B"]), K=from_dlpack(j["K"]), KT=from_dlpack(j.get("KT")))
+            for j in jobs]
     arr = (_lib.qk_gram_job * len(jobs))()
     dtype = jobs[0]["A"].dtype if jobs else torch.complex128
     if dtype not in (torch.complex128, torch.complex64):
@@ -118,6 +142,7 @@ def gram_jobs(jobs: Sequence[dict], D: int) -> None:
 
 def gram(psi_x: torch.Tensor, psi_y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K = |Psi_x Psi_y^H|^2; ``psi_y is None`` -> symmetric block with exact unit diagonal."""
+    psi_x, psi_y, out = from_dlpack(psi_x), from_dlpack(psi_y), from_dlpack(out)
     _require_gpu(psi_x, psi_y, out)
     N, D = psi_x.shape
     M = N if psi_y is None else psi_y.shape[0]
@@ -149,6 +174,7 @@ def block_to_host(K_dev: torch.Tensor, K_host: torch.Tensor, stream: Optional["t
 
 def rdm1(psi: torch.Tensor, n_qubits: int) -> torch.Tensor:
     """Per-qubit reduced density matrices, float64 [N, n, 4] = (rho00, rho11, Re rho01, Im rho01)."""
+    psi = from_dlpack(psi)
     _require_gpu(psi)
     if psi.dtype != torch.complex128 or not psi.is_contiguous() or psi.shape[1] != (1 << n_qubits):
         raise ValueError("psi must be contiguous complex128 [N, 2^n]")
@@ -160,6 +186,7 @@ def rdm1(psi: torch.Tensor, n_qubits: int) -> torch.Tensor:
 def pqk(rdm_x: torch.Tensor, rdm_y: Optional[torch.Tensor], gamma: float,
         out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Projected kernel block from RDM tables; ``rdm_y is None`` -> symmetric with unit diagonal."""
+    rdm_x, rdm_y, out = from_dlpack(rdm_x), from_dlpack(rdm_y), from_dlpack(out)
     _require_gpu(rdm_x, rdm_y, out)
     N, n, _ = rdm_x.shape
     M = N if rdm_y is None else rdm_y.shape[0]
@@ -174,6 +201,7 @@ def pqk(rdm_x: torch.Tensor, rdm_y: Optional[torch.Tensor], gamma: float,
 def kernel_stats(K: torch.Tensor, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw sums of the GA's kernel statistics over the strict upper triangle of a symmetric device
     K (see ``qk_kernel_stats_dev``): float64 [8] on the device."""
+    K, labels = from_dlpack(K), from_dlpack(labels)
     _require_gpu(K, labels)
     if K.dtype != torch.float64 or K.dim() != 2 or K.shape[0] != K.shape[1] or K.stride(1) != 1:
         raise ValueError("K must be a square float64 matrix with unit column stride")
@@ -192,6 +220,7 @@ def kernel_stats(K: torch.Tensor, labels: Optional[torch.Tensor] = None) -> torc
 def kernel_noise_(K: torch.Tensor, mode: str, param: float, seed: int = 0) -> torch.Tensor:
     """In-place noise on a symmetric device K: ``mode`` = "gaussian" (param = std, reference
     genetic_v3.py:620-627) or "shots" (param = shots, the QPU-style P(0...0) estimate)."""
+    K = from_dlpack(K)
     _require_gpu(K)
     if K.dtype != torch.float64 or K.dim() != 2 or K.shape[0] != K.shape[1] or K.stride(1) != 1:
         raise ValueError("K must be a square float64 matrix with unit column stride")

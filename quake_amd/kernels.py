@@ -102,7 +102,8 @@ class HipFidelityKernel:
     def __init__(self, feature_map: QuantumCircuit, *, enforce_psd: bool = False,
                  training_parameters: Optional[Sequence[Parameter]] = None,
                  parameter_values: Optional[Sequence[float]] = None,
-                 shots=None, cache_size=None, auto_clear_cache: bool = True, precision: str = "double"):
+                 shots=None, cache_size=None, auto_clear_cache: bool = True, precision: str = "double",
+                 seed: Optional[int] = None):
         if precision not in ("double", "single"):
             raise ValueError("precision must be 'double' or 'single'")
         # 'single': statevectors stored as complex64 and the Gram stage on FP32 MFMA (|dK| <= 1e-5); a
@@ -111,6 +112,10 @@ class HipFidelityKernel:
         if shots is not None and int(shots) < 1:
             raise ValueError("shots must be a positive integer")
         self._shots = int(shots) if shots is not None else None
+        # finite-shot draws: a counter-based generator keyed by (seed + call number, i, j).  The reference draws
+        # from numpy's unseeded global stream, so two kernel objects are independent there; here each object
+        # takes fresh entropy unless a seed is given (then its draws are reproducible)
+        self._shot_seed = (int(seed) if seed is not None else int(np.random.SeedSequence().entropy)) & (2**64 - 1)
         self._shot_calls = 0
         self._feature_map = feature_map
         self._training_parameters = list(training_parameters) if training_parameters is not None else []
@@ -190,10 +195,11 @@ class HipFidelityKernel:
         if self._shots is not None:
             # FidelityStatevectorKernel(shots=...): each entry becomes Binomial(shots, K_ij) / shots.
             # Sampled on the device (qk_kernel_noise_dev) for the symmetric matrix.
-            if y is not None:
-                raise NotImplementedError("finite-shot sampling is implemented for the symmetric (y_vec=None) matrix")
             self._shot_calls += 1
-            Ks, _ = evaluate_population([self._bound], [x], noise=("shots", self._shots), seed=self._shot_calls)
+            seed = (self._shot_seed + self._shot_calls) & (2**64 - 1)
+            if y is not None:
+                return self._sampled_cross_block(x, y, seed)
+            Ks, _ = evaluate_population([self._bound], [x], noise=("shots", self._shots), seed=seed)
             return Ks[0]
         lib = _lib.load()
         circ = self._circuit()
@@ -205,6 +211,14 @@ class HipFidelityKernel:
         _pin_equal_rows(K, x, y)
         if y is None and self._enforce_psd:
             K = self._make_psd(K)
+        return K
+
+    def _sampled_cross_block(self, x: np.ndarray, y: np.ndarray, seed: int) -> np.ndarray:
+        """Finite-shot estimate of a cross block: the exact block is embedded in the symmetric matrix of the stacked
+        rows [x; y], sampled there by the device epilogue (independent draws per entry) and cut out again."""
+        n, m = x.shape[0], y.shape[0]
+        Ks, _ = evaluate_population([self._bound], [np.concatenate([x, y], axis=0)], noise=("shots", self._shots), seed=seed)
+        K = np.ascontiguousarray(Ks[0][:n, n:])
         return K
 
     def statevectors(self, x_vec) -> np.ndarray:
@@ -332,5 +346,8 @@ def evaluate_population(feature_maps: Sequence[QuantumCircuit], x_vecs: Sequence
         opts = C.pointer(_lib.qk_batch_opts(code, 0, float(param), int(seed) & (2**64 - 1)))
     _lib.check(lib.qk_evaluate_batch(count, circ_arr, x_arr, n_arr, lab_arr, opts, k_arr,
                                      sums.ctypes.data if sums is not None else None))
+    if Ks is not None and noise is None:
+        for K, x in zip(Ks, xs):          # duplicate samples: exactly 1.0, as evaluate() and the reference have it
+            _pin_equal_rows(K, x, None)
     stats = [statistics_from_sums(sums[g], xs[g].shape[0]) for g in range(count)] if sums is not None else None
     return Ks, stats

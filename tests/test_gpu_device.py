@@ -115,3 +115,40 @@ def test_k_block_to_host_leg():
     torch.cuda.synchronize()
     assert torch.equal(host[5:35, 20:70], K[100:130, 7:57].cpu())
     assert (host[:5] == -1).all() and (host[35:] == -1).all() and (host[:, :20] == -1).all() and (host[:, 70:] == -1).all()
+
+
+class _ForeignArray:
+    """A non-torch DLPack producer: only the two protocol methods, as a cupy / jax / numba array would offer them."""
+    def __init__(self, t):
+        self._t = t
+
+    def __dlpack__(self, stream=None, **kw):
+        return self._t.__dlpack__(stream=stream) if stream is not None else self._t.__dlpack__()
+
+    def __dlpack_device__(self):
+        return self._t.__dlpack_device__()
+
+
+def test_dlpack_hand_off_in_and_out():
+    """Device entry points take any __dlpack__ producer or a raw capsule (zero copy) and hand back tensors that
+    are DLPack producers themselves."""
+    import torch
+    from quake_amd import device as qdev
+    n, N = 6, 90
+    torch_, dev, circ, oops, X = _setup(n, N, "zz_featuremap", 2)
+    Xd = torch.from_numpy(X).cuda()
+    psi = circ.simulate(_ForeignArray(Xd))                                  # a foreign object in
+    psi_caps = circ.simulate(torch.utils.dlpack.to_dlpack(Xd))              # a raw capsule in
+    assert torch.equal(psi, psi_caps) and torch.equal(psi, circ.simulate(Xd))
+    out = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    K = qdev.gram(_ForeignArray(psi), None, out=_ForeignArray(out))         # written through the foreign view: zero copy
+    assert K.data_ptr() == out.data_ptr()
+    assert np.abs(out.cpu().numpy() - O.evaluate(oops, n, X)).max() < 1e-12
+    back = torch.from_dlpack(qdev.to_dlpack(K))                             # and out again as a capsule
+    assert back.data_ptr() == K.data_ptr() and hasattr(K, "__dlpack__")
+    rd = qdev.rdm1(_ForeignArray(psi), n)
+    assert np.abs(qdev.pqk(_ForeignArray(rd), None, 0.5).cpu().numpy() - O.projected_kernel(oops, n, X, 0.5)).max() < 1e-12
+    with pytest.raises(ValueError):
+        circ.simulate(X)                                                    # numpy is a CPU DLPack producer: refused, no silent copy
+    with pytest.raises(TypeError):
+        qdev.gram([1, 2, 3])

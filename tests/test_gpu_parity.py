@@ -351,6 +351,7 @@ def test_projected_kernel_distance_scales():
     N, n = 700, 6
     for scale in (1.0, 1e-3, 1e-6, 1e-9, 1e-12, 0.0):
         r = rng.uniform(-1, 1, size=(1, n, 4)) + scale * rng.uniform(-1, 1, size=(N, n, 4))
+        r[..., 1] = 1.0 - r[..., 0]       # unit trace, as every density matrix has it: the kernel relies on d rho11 = -d rho00
         K = dev.pqk(torch.from_numpy(r).cuda(), None, 1.0).cpu().numpy()
         d = (r[:, None] - r[None]).astype(np.longdouble)
         fro = np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2 + 2 * (d[..., 2] ** 2 + d[..., 3] ** 2))
