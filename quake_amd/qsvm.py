@@ -151,3 +151,38 @@ def qsvm_train_from_features(features, labels, train_folder, setup: dict, seed: 
                                           final_kernel=q.get("final_kernel", "rbf"))
     metrics = evaluate_svm(models, dataset, labels, kernels)
     return models, metrics
+
+
+def load_feature_files(data_folder) -> Tuple[list, list]:
+    """``[train, val, test]`` features and labels from ``features_<split>.npy`` /
+    ``labels_<split>.npy`` under ``data_folder`` (what an upstream extractor run saves;
+    stands in for reference ``train.py:221-240``).  Plain arrays only: no pickles."""
+    data_folder = Path(data_folder)
+    feats, labs = [], []
+    for split in ("train", "val", "test"):
+        fx, fy = data_folder / f"features_{split}.npy", data_folder / f"labels_{split}.npy"
+        if not fx.is_file() or not fy.is_file():
+            raise FileNotFoundError(f"expected {fx.name} and {fy.name} in {data_folder}")
+        x = np.load(fx, allow_pickle=False)
+        y = np.load(fy, allow_pickle=False)
+        if x.ndim != 2 or y.ndim != 1 or x.shape[0] != y.shape[0]:
+            raise ValueError(f"{split}: features {x.shape} and labels {y.shape} do not match")
+        feats.append(np.asarray(x, dtype=np.float64))
+        labs.append(y)
+    if len({f.shape[1] for f in feats}) != 1:
+        raise ValueError("train / val / test features differ in width")
+    return feats, labs
+
+
+def qsvm_train(data_folder, train_folder, setup: dict):
+    """Drop-in for the reference's ``qsvm_train(data_folder, train_folder, setup)``
+    (train.py:190-272) with the feature extraction replaced by
+    :func:`load_feature_files`; everything from ``rearrange_scale`` on is the reference's
+    sequence, with the Gram matrices computed on the GPU."""
+    extractor_type = str(setup["model"]["qsvm"].get("feature_extractor", "npy")).lower()
+    if extractor_type not in ("npy", "cnn", "attention"):
+        raise NotImplementedError(f"exctractor model not implemented, found: {extractor_type}")
+    features, labels = load_feature_files(data_folder)
+    train_folder = Path(train_folder)
+    train_folder.mkdir(parents=True, exist_ok=True)
+    return qsvm_train_from_features(features, labels, train_folder, setup)

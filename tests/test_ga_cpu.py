@@ -119,3 +119,25 @@ def test_artifact_files(tmp_path):
     assert np.loadtxt(d / "best_solution.txt").shape == (2,)
     assert (d / "best_fitness_per_generation.txt").read_text().startswith("[")
     assert np.load(d / "data_cv.npy").shape == (3, 2) and np.load(d / "labels_cv.npy").shape == (3,)
+
+
+def test_load_feature_files_checks(tmp_path):
+    """the .npy stand-in for the reference's extractor stage (train.py:221-240): plain arrays,
+    matching lengths and widths, loud errors otherwise"""
+    import numpy as np
+    from quake_amd import qsvm
+    with pytest.raises(FileNotFoundError):
+        qsvm.load_feature_files(tmp_path)
+    for s, n in (("train", 6), ("val", 4), ("test", 3)):
+        np.save(tmp_path / f"features_{s}.npy", np.zeros((n, 3), dtype=np.float32))
+        np.save(tmp_path / f"labels_{s}.npy", np.arange(n) % 2)
+    feats, labs = qsvm.load_feature_files(tmp_path)
+    assert [f.shape for f in feats] == [(6, 3), (4, 3), (3, 3)] and feats[0].dtype == np.float64
+    assert [len(y) for y in labs] == [6, 4, 3]
+    np.save(tmp_path / "labels_val.npy", np.zeros(5))
+    with pytest.raises(ValueError):
+        qsvm.load_feature_files(tmp_path)
+    np.save(tmp_path / "labels_val.npy", np.zeros(4))
+    np.save(tmp_path / "features_test.npy", np.zeros((3, 2)))
+    with pytest.raises(ValueError):
+        qsvm.load_feature_files(tmp_path)

@@ -50,6 +50,28 @@ def test_train_and_evaluate_match_oracle(tmp_path):
     assert m2[0].kernel == "precomputed" and models[0].kernel == "rbf"
 
 
+def test_qsvm_train_from_npy_folder(tmp_path):
+    """reference train.py:190-272 with the extractor replaced by .npy files: same models as the
+    in-memory entry on the same arrays"""
+    data = tmp_path / "data"
+    data.mkdir()
+    sets = {s: _toy(seed, n, F=3) for s, seed, n in (("train", 7, 90), ("val", 8, 40), ("test", 9, 30))}
+    for s, (x, y) in sets.items():
+        np.save(data / f"features_{s}.npy", x)
+        np.save(data / f"labels_{s}.npy", y)
+    setup = {"model": {"qsvm": {"feature_extractor": "cnn", "should_do_scaling": True, "split_ratio": 0.5,
+                                "should_add_extra_feats": False, "feature_maps": [["zz", {"repeats": 1}]]}}}
+    models, metrics = qsvm.qsvm_train(data, tmp_path / "out", setup)
+    assert (tmp_path / "out" / "zz.sav").exists()
+    m2, metrics2 = qsvm.qsvm_train_from_features([sets[s][0] for s in ("train", "val", "test")],
+                                                 [sets[s][1] for s in ("train", "val", "test")], None, setup)
+    assert np.array_equal(metrics["accuracy"], metrics2["accuracy"])
+    assert models[0].C == m2[0].C
+    setup["model"]["qsvm"]["feature_extractor"] = "svm"
+    with pytest.raises(NotImplementedError):
+        qsvm.qsvm_train(data, tmp_path / "out", setup)
+
+
 def test_runcard_feature_maps(tmp_path):
     card = tmp_path / "runcard.yaml"
     card.write_text("output: !Path out\nmodel:\n  qsvm:\n    should_do_scaling: true\n    split_ratio: 0.6\n"
