@@ -173,7 +173,10 @@ def gram_kernel_name(rows, D):
     name = lib.qk_gram_variant_for(rows, D).decode()
     return {"dma3m_128x128_w8": "qk::gram_dma_kernel<2,4,4,2,true> (128x128 tiles)",
             "dma3m_64x64_w4": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles)",
-            "dma3m_64x64_w4_g64": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles, 8x8 tile groups)"}.get(name, name)
+            "dma3m_64x64_w4_g64": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles, 8x8 tile groups)",
+            "lean3m_64x64_w4": "qk::gram_lean_kernel<2,2,2,2,0> (64x64 tiles)",
+            "ring3_64x64_w4": "qk::gram_ring_kernel<3> (64x64 tiles, 3-stage LDS ring, 3 workgroups per CU)",
+            "ring5_64x64_w4": "qk::gram_ring_kernel<5> (64x64 tiles, 5-stage LDS ring, 2 workgroups per CU)"}.get(name, name)
 
 
 def pmc_traffic_committed(N, n, repeats, world):

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "qk_common.h"
 
@@ -53,6 +54,8 @@ struct GramArgs {
     int n_jobs;
     int lr, lc;  // log2 of the macro-tile shape in block tiles (rows, columns): 4 x 8 for 128 x 128 tiles
     int64_t D;  // amplitudes per row
+    int64_t ld; // row stride of A and B in amplitudes (>= D)
+    double* trace;  // timeline builds only (QK_GRAM_ABLATE & 128): 8 doubles per workgroup
 };
 
 // Which block tile does this workgroup compute?  Returns false for padding workgroups.
@@ -116,6 +119,15 @@ __device__ __forceinline__ bool gram_locate(const GramArgs& args, GramJobDev& J,
     return true;
 }
 
+// Measurement builds only (tools/gram_ablate.sh compiles this file again with -DQK_GRAM_ABLATE=mask into a
+// separate library; the results of such a build are wrong on purpose): bit 0 drops the in-loop DMA, bit 1 the
+// in-loop barrier, bit 2 the in-loop fragment reads (and with them the two VALU adds per fragment), bit 3 points
+// every in-loop DMA at k-tile 0 (always an L2 hit), bit 4 drops the VALU adds only, bit 5 all stores of the epilogue, bit 6 its mirror
+// stores (bits 5 and 6 act on every kernel, bits 0-4 on gram_dma_kernel only).
+#ifndef QK_GRAM_ABLATE
+#define QK_GRAM_ABLATE 0
+#endif
+
 // |.|^2 and the stores.  f64 16x16x4 result layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
 template <int TM, int TN, bool K3M, int NACC>
 __device__ __forceinline__ void gram_epilogue(v4d (&acc)[NACC][TM][TN], const GramJobDev& J, int64_t wrow0,
@@ -145,8 +157,9 @@ __device__ __forceinline__ void gram_epilogue(v4d (&acc)[NACC][TM][TN], const Gr
                     if (i > j) continue;      // below the diagonal: written by the mirror store
                     if (i == j) v = 1.0;      // identical statevectors stay exactly 1
                 }
+                if (QK_GRAM_ABLATE & 32) { if (v == 123.456) Kp[0] = v; continue; }
                 Kp[i * ldk + j] = v;
-                if (sym && i != j) Kp[j * ldk + i] = v;
+                if (sym && i != j && !(QK_GRAM_ABLATE & 64)) Kp[j * ldk + i] = v;
                 if (KTp) KTp[j * ldkt + i] = v;
             }
 }
@@ -458,7 +471,7 @@ gram_dma_kernel(GramArgs args) {
         const int cur = (int)(kt & 1);
         // next k-tile straight into the other buffer (nobody reads it during this k-tile);
         // the last iteration re-reads its own tile: branch-free and harmless
-        const int64_t noff = min(kt + 1, ktiles - 1) * C::BK;
+        const int64_t noff = (QK_GRAM_ABLATE & 8) ? 0 : min(kt + 1, ktiles - 1) * C::BK;
         const v2d* S = smem + cur * C::BUF;
         const v2d* Sn = smem + (cur ^ 1) * C::BUF;
 #pragma unroll
@@ -468,16 +481,16 @@ gram_dma_kernel(GramArgs args) {
                 // issued (a, b are dead then) and before P3, also across the barrier
                 double sa[TM], db[TN];
 #pragma unroll
-                for (int m = 0; m < TM; ++m) sa[m] = a[m].x + a[m].y;
+                for (int m = 0; m < TM; ++m) sa[m] = (QK_GRAM_ABLATE & 16) ? a[m].x : a[m].x + a[m].y;
 #pragma unroll
-                for (int n = 0; n < TN; ++n) db[n] = b[n].y - b[n].x;
+                for (int n = 0; n < TN; ++n) db[n] = (QK_GRAM_ABLATE & 16) ? b[n].y : b[n].y - b[n].x;
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
                         acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < 3) issue_dma(cur ^ 1, noff, kk);
+                if (kk < 3 && !(QK_GRAM_ABLATE & 1)) issue_dma(cur ^ 1, noff, kk);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
@@ -486,16 +499,20 @@ gram_dma_kernel(GramArgs args) {
                         acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk < KS - 1) {
+                    if (!(QK_GRAM_ABLATE & 4)) {
 #pragma unroll
-                    for (int m = 0; m < TM; ++m) a[m] = S[a_row + m * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+                        for (int m = 0; m < TM; ++m) a[m] = S[a_row + m * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
 #pragma unroll
-                    for (int n = 0; n < TN; ++n) b[n] = S[b_row + n * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+                        for (int n = 0; n < TN; ++n) b[n] = S[b_row + n * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+                    }
                 } else {
-                    __syncthreads();
+                    if (!(QK_GRAM_ABLATE & 2)) __syncthreads();
+                    if (!(QK_GRAM_ABLATE & 4)) {
 #pragma unroll
-                    for (int m = 0; m < TM; ++m) a[m] = Sn[a_row + m * 256 + xs[0]];
+                        for (int m = 0; m < TM; ++m) a[m] = Sn[a_row + m * 256 + xs[0]];
 #pragma unroll
-                    for (int n = 0; n < TN; ++n) b[n] = Sn[b_row + n * 256 + xs[0]];
+                        for (int n = 0; n < TN; ++n) b[n] = Sn[b_row + n * 256 + xs[0]];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -543,6 +560,328 @@ gram_dma_kernel(GramArgs args) {
         }
     }
     gram_epilogue<TM, TN, K3M>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
+}
+
+// ---- "lean" LDS-DMA kernel: the same tiles, arithmetic and LDS image as gram_dma_kernel, with the inner loop
+// stripped of vector-ALU work.  Ablation builds of gram_dma_kernel (tools/gram_ablate.sh) showed
+// that every VALU instruction a wave issues between its MFMAs costs matrix-pipe time (the FP64 MFMA and the FP64
+// vector ALU are the same multipliers; 4 v_add_f64 per k-step = 2.4 %, the 64-bit address adds and readfirstlanes
+// around each DMA instruction another 3.6 %).  Here
+//   * DMA sources are  SGPR base (advanced per k-tile on the scalar ALU) + a per-lane 32-bit offset that never
+//     changes, the LDS destinations are scalar (wave index through readfirstlane once),
+//   * fragment reads use 2 x KS precomputed per-lane LDS addresses with immediate offsets; the k-tile loop is
+//     unrolled by two so that the buffer a k-tile lives in is a compile-time constant,
+//   * loop control is 32-bit scalar,
+// which leaves the TM + TN fragment sums as the only vector-ALU instructions of a k-step.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int SCHED>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
+gram_lean_kernel(GramArgs args) {
+    using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, true>;
+    constexpr int KS = 4;
+    constexpr int NE = C::NA + C::NB;
+    extern __shared__ v2d smem[];  // [2 buffers][A: BM x 16 | B: BN x 16]
+    GramJobDev J;
+    int ti, tj;
+    if (!gram_locate(args, J, ti, tj)) return;
+    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+
+    [[maybe_unused]] const uint64_t t_start = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const uint32_t D = (uint32_t)args.D, LD = (uint32_t)args.ld;   // the host checks ld <= 2^22: 63 rows x ld x 16 B fit 32 bits
+    const int64_t row0 = (int64_t)ti * C::BM, col0 = (int64_t)tj * C::BN;
+    const int64_t ma = J.ma, nb = J.nb;
+
+    // per-lane byte offsets of this wave's DMA instructions from the tile's first A / B row (rows past the
+    // end are clamped to the last one: their results are never stored)
+    uint32_t vo[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int j = e < C::NA ? e : e - C::NA;
+        const int row = 4 * (wave + C::WAVES * j) + (lane >> 4);
+        const int64_t first = e < C::NA ? row0 : col0, last = (e < C::NA ? ma : nb) - 1;
+        const uint32_t rr = (uint32_t)(min(first + row, last) - first);
+        vo[e] = (rr * LD + (uint32_t)((lane & 15) ^ (row & 15))) * 16u;
+    }
+    const char* Ab = (const char*)J.A + row0 * (int64_t)LD * 16;   // wave-uniform: scalar registers
+    const char* Bb = (const char*)J.B + col0 * (int64_t)LD * 16;
+    char* const lds = (char*)smem;
+    // DMA instruction e of this wave into buffer `buf`, source k-tile at byte offset koff of every row
+    auto dma = [&](int buf, uint32_t koff, int e) __attribute__((always_inline)) {
+        const int j = e < C::NA ? e : e - C::NA;
+        const char* src = (e < C::NA ? Ab : Bb) + koff;
+        char* dst = lds + buf * (C::BUF * 16) + (e < C::NA ? 0 : C::BM * 256) + (wave + C::WAVES * j) * 1024;
+        // (scalar base) + zext(32-bit lane offset) selects the SGPR-base form of the instruction; the empty asm
+        // keeps the zero-extension inside the loop body, where instruction selection can see it
+        asm volatile("" : "+v"(vo[e]));
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + (uint64_t)vo[e]), (lptr_t)dst, 16, 0, 0);
+    };
+    auto dma_part = [&](int buf, uint32_t koff, int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const bool mine = SCHED == 0 ? (e % 3) == kk : SCHED == 1 ? (e / ((NE + 1) / 2)) == kk : kk == 0;
+            if (mine) dma(buf, koff, e);
+        }
+    };
+
+    v4d acc[3][TM][TN];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[c][m][n] = (v4d){0, 0, 0, 0};
+
+    const int ktiles = (int)(D >> 4);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) dma(0, 0, e);
+    __syncthreads();
+
+    // fragment byte addresses in buffer 0: element (row * 16 + ((4 kk + lane>>4) ^ (lane & 15)))
+    const int frag_k = lane >> 4, frag_r = lane & 15;
+    typedef const __attribute__((address_space(3))) v2d* lfrag_t;
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;    // the LDS address of the image, folded into fa / fb once
+    uint32_t fa[KS], fb[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int x = (4 * kk + frag_k) ^ frag_r;
+        fa[kk] = lds0 + (uint32_t)(((wm * (TM * 16) + frag_r) * 16 + x) * 16);
+        fb[kk] = lds0 + (uint32_t)((C::BM * 16 + (wn * (TN * 16) + frag_r) * 16 + x) * 16);
+        asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));   // opaque: otherwise the sums are redone per read
+    }
+    v2d a[TM], b[TN];
+    auto read_frags = [&](int buf, int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) a[m] = *(lfrag_t)(size_t)(fa[kk] + (uint32_t)(buf * C::BUF * 16 + m * 4096));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) b[n] = *(lfrag_t)(size_t)(fb[kk] + (uint32_t)(buf * C::BUF * 16 + n * 4096));
+    };
+    read_frags(0, 0);
+    [[maybe_unused]] const uint64_t t_first = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
+
+    // one k-tile out of buffer CUR while the DMA fills the other one with the k-tile at row offset koff
+    auto ktile = [&](auto cur_c, uint32_t koff) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            double sa[TM], db[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m) sa[m] = a[m].x + a[m].y;
+#pragma unroll
+            for (int n = 0; n < TN; ++n) db[n] = b[n].y - b[n].x;
+            if (kk < KS - 1) dma_part(CUR ^ 1, koff, kk);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk < KS - 1) {
+                read_frags(CUR, kk + 1 < KS ? kk + 1 : 0);
+            } else {
+                __syncthreads();
+                read_frags(CUR ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[2][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[m], db[n], acc[2][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // the last k-tile re-reads itself into the idle buffer: branch-free and harmless
+    int kt = 0;
+    for (; kt + 2 <= ktiles; kt += 2) {
+        ktile(std::integral_constant<int, 0>{}, (uint32_t)min(kt + 1, ktiles - 1) * 256u);
+        ktile(std::integral_constant<int, 1>{}, (uint32_t)min(kt + 2, ktiles - 1) * 256u);
+    }
+    if (kt < ktiles) ktile(std::integral_constant<int, 0>{}, (uint32_t)(ktiles - 1) * 256u);
+    if constexpr ((QK_GRAM_ABLATE & 128) != 0) {
+        // timeline build: wave 0 of every workgroup leaves its 100 MHz timestamps and where it ran in the first
+        // row of a side table the tool passes as KT of a non-symmetric job (8 doubles per workgroup)
+        const uint64_t t_loop = wall_clock64();
+        gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t t_end = wall_clock64();
+        if (tid == 0 && args.trace) {
+            double* o = args.trace + (int64_t)blockIdx.x * 8;
+            o[0] = (double)t_start; o[1] = (double)t_first; o[2] = (double)t_loop; o[3] = (double)t_end;
+            o[4] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+            o[5] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+            o[6] = (double)ti; o[7] = (double)tj;
+        }
+        return;
+    }
+    gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
+}
+
+// ---- "ring" LDS-DMA kernel: the lean inner loop over stages of 8 amplitudes in a ring of NST 16 KiB buffers.
+// The DMA of stage h + NST - 1 is issued while stage h is computed and only stage h + 1 is waited for
+// (s_waitcnt vmcnt(4 (NST - 2)): the younger DMA instructions of the wave stay in flight across the barrier), so a
+// load has NST - 1 stages to arrive instead of the remainder of one k-tile.  NST = 3: 48 KiB of LDS, THREE workgroups
+// per CU (three waves per SIMD) -- for short rows, where a tile is over in tens of microseconds and its prologue,
+// epilogue and the restart of the slot (measured with the timeline build: 1, 3.5 and 6 us of a 49 us tile at D = 256)
+// have to hide behind the other workgroups of the CU.  NST = 5: 80 KiB, two workgroups per CU, four stages of
+// prefetch -- for long rows, where the working set of a third workgroup costs more in L2 than it hides.
+// LDS image of a stage: [A: 64 rows | B: 64 rows] x 128 bytes; one DMA instruction fills 8 rows; slot s of row r
+// holds amplitude s ^ ((r >> 1) & 7), which spreads the 16 rows x one k-slot of a fragment read over all 64 banks.
+template <int NST>
+__global__ void __launch_bounds__(256, NST == 3 ? 3 : 2)
+gram_ring_kernel(GramArgs args) {
+    constexpr int TM = 2, TN = 2, WAVES_N = 2, WAVES = 4, BM = 64, BN = 64;
+    constexpr int STAGE = (BM + BN) * 128;          // bytes
+    constexpr int NA = BM / 8 / WAVES, NB = BN / 8 / WAVES, NE = NA + NB;
+    constexpr int INFLIGHT = NE * (NST - 2);        // DMA instructions of a wave that may stay in flight at a barrier
+    static_assert(NST == 3 || NST == 5, "ring of 3 or 5 stages");
+    extern __shared__ v2d smem[];  // [NST stages][A | B]
+    GramJobDev J;
+    int ti, tj;
+    if (!gram_locate(args, J, ti, tj)) return;
+    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const uint32_t D = (uint32_t)args.D, LD = (uint32_t)args.ld;   // the host checks ld <= 2^22: 63 rows x ld x 16 B fit 32 bits
+    const int64_t row0 = (int64_t)ti * BM, col0 = (int64_t)tj * BN;
+    const int64_t ma = J.ma, nb = J.nb;
+
+    uint32_t vo[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int j = e < NA ? e : e - NA;
+        const int row = 8 * (wave + WAVES * j) + (lane >> 3);
+        const int64_t first = e < NA ? row0 : col0, last = (e < NA ? ma : nb) - 1;
+        const uint32_t rr = (uint32_t)(min(first + row, last) - first);
+        vo[e] = (rr * LD + (uint32_t)((lane & 7) ^ ((row >> 1) & 7))) * 16u;
+    }
+    const char* Ab = (const char*)J.A + row0 * (int64_t)LD * 16;   // wave-uniform: scalar registers
+    const char* Bb = (const char*)J.B + col0 * (int64_t)LD * 16;
+    char* const lds = (char*)smem;
+    auto dma = [&](int buf, uint32_t koff, int e) __attribute__((always_inline)) {
+        const int j = e < NA ? e : e - NA;
+        const char* src = (e < NA ? Ab : Bb) + koff;
+        char* dst = lds + buf * STAGE + (e < NA ? 0 : BM * 128) + (wave + WAVES * j) * 1024;
+        asm volatile("" : "+v"(vo[e]));   // keeps zext(lane offset) in the loop body: selects the SGPR-base form
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + (uint64_t)vo[e]), (lptr_t)dst, 16, 0, 0);
+    };
+    // stage h + 1 has landed for this wave (its own DMA instructions complete in order), then for all of them
+    auto wait_next_stage = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+    };
+
+    v4d acc[3][TM][TN];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[c][m][n] = (v4d){0, 0, 0, 0};
+
+    const int stages = (int)(D >> 3);
+    const int lastst = stages - 1;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dma(s, (uint32_t)min(s, lastst) * 128u, e);
+    wait_next_stage();   // here: stage 0
+
+    const int frag_k = lane >> 4, frag_r = lane & 15;
+    typedef const __attribute__((address_space(3))) v2d* lfrag_t;
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+    uint32_t fa[2], fb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int x = (4 * kk + frag_k) ^ (frag_r >> 1);
+        fa[kk] = lds0 + (uint32_t)((wm * (TM * 16) + frag_r) * 128 + x * 16);
+        fb[kk] = lds0 + (uint32_t)(BM * 128 + (wn * (TN * 16) + frag_r) * 128 + x * 16);
+        asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));   // opaque: otherwise the sums are redone per read
+    }
+    v2d a[TM], b[TN];
+    auto read_frags = [&](int buf, int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) a[m] = *(lfrag_t)(size_t)(fa[kk] + (uint32_t)(buf * STAGE + m * 2048));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) b[n] = *(lfrag_t)(size_t)(fb[kk] + (uint32_t)(buf * STAGE + n * 2048));
+    };
+    read_frags(0, 0);
+
+    // stage hh out of buffer S; the DMA of stage hh + NST - 1 goes into buffer S - 1 (mod NST), which every wave
+    // left behind at the last barrier.  Past the end the DMA re-reads the last stage into a buffer nobody reads
+    // any more: branch-free and harmless.
+    auto stage = [&](auto s_c, int hh) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value;
+        const uint32_t koff = (uint32_t)min(hh + NST - 1, lastst) * 128u;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            double sa[TM], db[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m) sa[m] = a[m].x + a[m].y;
+#pragma unroll
+            for (int n = 0; n < TN; ++n) db[n] = b[n].y - b[n].x;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if ((e & 1) == kk) dma((S + NST - 1) % NST, koff, e);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk == 0) {
+                read_frags(S, 1);
+            } else {
+                wait_next_stage();
+                read_frags((S + 1) % NST, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[2][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[m], db[n], acc[2][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using std::integral_constant;
+    int h = 0;
+    for (; h + NST <= stages; h += NST) {
+        stage(integral_constant<int, 0>{}, h);
+        stage(integral_constant<int, 1>{}, h + 1);
+        stage(integral_constant<int, 2>{}, h + 2);
+        if constexpr (NST == 5) {
+            stage(integral_constant<int, 3>{}, h + 3);
+            stage(integral_constant<int, 4>{}, h + 4);
+        }
+    }
+    // the stage count is a power of two: 1 .. NST - 1 stages are left, starting in buffer 0 again
+    if (h < stages) stage(integral_constant<int, 0>{}, h);
+    if (h + 1 < stages) stage(integral_constant<int, 1>{}, h + 1);
+    if constexpr (NST == 5) {
+        if (h + 2 < stages) stage(integral_constant<int, 2>{}, h + 2);
+        if (h + 3 < stages) stage(integral_constant<int, 3>{}, h + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be writing this workgroup's LDS when it ends
+    gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
 }
 
 // ---- FP32 variant (optional precision of BASELINE.json north_star; tolerance 1e-5) -------------
@@ -794,6 +1133,25 @@ void launch_dma_variant(const GramArgs& args, unsigned blocks, hipStream_t strea
             (const void*)gram_dma_kernel<WM, WN, TM, TN, K3M>, launch_dma_variant<WM, WN, TM, TN, K3M>     \
     }
 
+template <int WAVES_M, int WAVES_N, int TM, int TN, int SCHED>
+void launch_lean_variant(const GramArgs& args, unsigned blocks, hipStream_t stream) {
+    using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, true>;
+    hipLaunchKernelGGL((gram_lean_kernel<WAVES_M, WAVES_N, TM, TN, SCHED>), dim3(blocks), dim3(C::THREADS), C::LDS_BYTES,
+                       stream, args);
+}
+
+#define QK_LEAN_VARIANT(NAME, WM, WN, TM, TN, SCHED, LR, LC)                                               \
+    Variant {                                                                                              \
+        NAME, GramDmaCfg<WM, WN, TM, TN, true>::BM, GramDmaCfg<WM, WN, TM, TN, true>::BN,                  \
+            GramDmaCfg<WM, WN, TM, TN, true>::THREADS, 16, LR, LC, GramDmaCfg<WM, WN, TM, TN, true>::LDS_BYTES, \
+            (const void*)gram_lean_kernel<WM, WN, TM, TN, SCHED>, launch_lean_variant<WM, WN, TM, TN, SCHED> \
+    }
+
+template <int NST>
+void launch_ring_variant(const GramArgs& args, unsigned blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((gram_ring_kernel<NST>), dim3(blocks), dim3(256), NST * 128 * 128, stream, args);
+}
+
 static const Variant kVariants[] = {
     QK_VARIANT("4m_128x128_w8_bk8", 2, 4, 4, 2, 8, false),
     QK_VARIANT("4m_128x128_w8_bk16", 2, 4, 4, 2, 16, false),
@@ -802,18 +1160,21 @@ static const Variant kVariants[] = {
     QK_DMA_VARIANT("dma3m_64x64_w4", 2, 2, 2, 2, true, 2, 3),    // two independent workgroups per CU
     QK_DMA_VARIANT("dma3m_64x64_w4_g64", 2, 2, 2, 2, true, 3, 3),  // ... whose 64 tiles per XCD form ONE 8 x 8 group
     QK_DMA_VARIANT("dma3m_64x64_w4_g4x16", 2, 2, 2, 2, true, 2, 4),
+    QK_LEAN_VARIANT("lean3m_64x64_w4", 2, 2, 2, 2, 0, 3, 3),      // the round-1 geometry with the lean inner loop
+    Variant{"ring3_64x64_w4", 64, 64, 256, 8, 3, 3, 3 * 128 * 128, (const void*)gram_ring_kernel<3>, launch_ring_variant<3>},   // three workgroups per CU
+    Variant{"ring5_64x64_w4", 64, 64, 256, 8, 3, 3, 5 * 128 * 128, (const void*)gram_ring_kernel<5>, launch_ring_variant<5>},   // two per CU, four stages of prefetch
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-// Default, from in-process A/B runs (tools/gram_ab.py, tools/shard_ab.py): dma3m_64x64_w4_g64 for every
-// shape.  Two independent 4-wave workgroups per CU: one keeps the matrix pipe busy while the other sits at
-// its barrier, and small problems split into 4x as many tiles.  With the packed tile schedule (gram_locate)
-// it also wins at the headline size (N = 65536, n = 16: 12.50 s against 13.05 s for dma3m_128x128_w8 on
-// the same box; under the older macro-tile schedule with its dead tiles the 128 x 128 tiles were 1.3 %
-// ahead there).  N = 4096, n = 8: +34 % over 128 x 128.
-constexpr int kDefaultVariant = 5;   // dma3m_64x64_w4_g64
+// Default, from in-process A/B runs (tools/gram_ab.py): the ring kernels, three stages and three
+// workgroups per CU for rows of up to 1024 amplitudes, five stages and two workgroups per CU above.  All variants
+// give bitwise identical results (same tiles, same summation order).  dma3m_64x64_w4_g64 was the round-1 default
+// and serves rows beyond 2^22 amplitudes, where the 32-bit lane offsets of the lean and ring kernels end.
+constexpr int kRing3Variant = 8, kRing5Variant = 9;
+constexpr int kFallbackVariant = 5;
 
 static std::atomic<int> g_variant{-1};       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = the default
 static std::atomic<bool> g_env_read{false};
+static std::atomic<double*> g_trace{nullptr};  // timeline builds only
 static DeviceOnce g_attr_set[kNumVariants];
 
 static int pick_variant(const qk_gram_job* jobs, int n_jobs, int64_t D) {
@@ -824,8 +1185,8 @@ static int pick_variant(const qk_gram_job* jobs, int n_jobs, int64_t D) {
     }
     const int forced = g_variant.load();
     if (forced >= 0) return forced;
-    (void)jobs; (void)n_jobs; (void)D;
-    return kDefaultVariant;
+    (void)jobs; (void)n_jobs;
+    return D <= 1024 ? kRing3Variant : kRing5Variant;
 }
 
 }  // namespace qk
@@ -848,6 +1209,9 @@ extern "C" int qk_gram_set_variant(const char* name) {
     return fail(QK_ERR_INVALID, "qk_gram_set_variant: unknown variant");
 }
 
+// timeline builds (QK_GRAM_ABLATE & 128) only: device table of 8 doubles per workgroup of the next launches
+extern "C" void qk_gram_set_trace(double* table_dev) { qk::g_trace = table_dev; }
+
 extern "C" const char* qk_gram_variant_for(int64_t rows, int64_t D) {
     using namespace qk;
     qk_gram_job j;
@@ -866,6 +1230,7 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
     if (D < 1 || (D & (D - 1)) != 0) return fail(QK_ERR_INVALID, std::string(who) + ": D must be a power of two");
     std::memset(&args, 0, sizeof(args));
     args.D = D;
+    args.ld = D;
     args.lr = lr;
     args.lc = lc;
     blocks = 0;
@@ -915,6 +1280,8 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
     using namespace qk;
     int vi = pick_variant(jobs, n_jobs, D);
     if (D < kVariants[vi].min_d) vi = 0;  // LDS-DMA tiles need 16 amplitudes per k-tile; tiny circuits use variant 0
+    if (D > ((int64_t)1 << 22) && (std::strncmp(kVariants[vi].name, "lean", 4) == 0 || std::strncmp(kVariants[vi].name, "ring", 4) == 0))
+        vi = kFallbackVariant;  // 32-bit lane offsets
     const Variant& V = kVariants[vi];
     GramArgs args;
     int64_t blocks = 0;
@@ -925,6 +1292,9 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
         QK_HIP(hipFuncSetAttribute(V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds));
         g_attr_set[vi].done();
     }
+    if (QK_GRAM_ABLATE & 128) args.trace = g_trace.load();
+    static const int64_t ld_env = std::getenv("QK_GRAM_LD") ? std::atoll(std::getenv("QK_GRAM_LD")) : 0;   // experiment
+    if (ld_env >= D) args.ld = ld_env;
     V.launch(args, (unsigned)blocks, (hipStream_t)stream);
     QK_HIP(hipGetLastError());
     return QK_OK;
