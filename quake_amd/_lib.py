@@ -200,6 +200,16 @@ class CircuitHandle:
     def num_passes(self) -> int:
         return load().qk_circuit_num_passes(self._h)
 
+    @property
+    def plan_summary(self) -> str:
+        """What the planner made of the gate list (development hook; text)."""
+        lib = load()
+        lib.qk_circuit_plan_summary.restype = C.c_int
+        lib.qk_circuit_plan_summary.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        buf = C.create_string_buffer(512)
+        check(lib.qk_circuit_plan_summary(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:

@@ -1,6 +1,8 @@
 // C ABI glue: error reporting, circuit handles and the host-pointer entry points.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include <algorithm>
 #include <cstring>
 #include <mutex>
@@ -126,6 +128,13 @@ extern "C" void qk_circuit_destroy(qk_circuit* c) {
 extern "C" int qk_circuit_num_qubits(const qk_circuit* c) { return c ? c->n_qubits : QK_ERR_INVALID; }
 extern "C" int qk_circuit_num_params(const qk_circuit* c) { return c ? c->n_params : QK_ERR_INVALID; }
 extern "C" int qk_circuit_num_passes(const qk_circuit* c) { return c ? (int)c->passes.size() : QK_ERR_INVALID; }
+
+// Development hook (not in the public header): what the planner made of the gate list, as text.
+extern "C" int qk_circuit_plan_summary(const qk_circuit* c, char* buf, int len) {
+    if (!c || !buf || len < 1) return QK_ERR_INVALID;
+    std::snprintf(buf, (size_t)len, "%s; passes %d", c->plan_summary.c_str(), (int)c->passes.size());
+    return QK_OK;
+}
 
 extern "C" int qk_host_alloc(size_t bytes, void** out) {
     using namespace qk;

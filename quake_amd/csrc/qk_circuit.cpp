@@ -6,10 +6,15 @@
 //      reference quantum_featuremaps.py:75-78) -- same multiplications, no swaps;
 //   2. merges runs of diagonal gates (p, rz, cz, the term above) into one DIAG stage,
 //      letting diagonal gates sink past later non-diagonal gates they commute with;
+//   1b. multiplies runs of single-qubit gates on one qubit (two or more of them non-diagonal, nothing
+//      two-qubit in between) into ONE 2x2 matrix per sample (QK_UC) -- a GA genome circuit draws a
+//      gate per qubit and layer and only a few cx, so most of it collapses into the initial
+//      product state and a handful of general single-qubit gates;
 //   3. splits the stage list into passes whose non-diagonal gates only touch
 //      "local" qubits (<= 13, the part of the state one workgroup keeps in LDS).
 #include <algorithm>
 #include <cstring>
+#include <string>
 
 #include "qk_common.h"
 #include "qk_wave.h"
@@ -75,6 +80,50 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     }
     c.n_gates = (int)items.size();
 
+    // ---- 1b. runs of single-qubit gates on one qubit -> one composite matrix -------------------
+    // chain[q]: the single-qubit items on q since the last two-qubit item that touched q.  Gates on
+    // different qubits commute, so a chain may be emitted as a block right before the next two-qubit
+    // item on its qubit (or at the end).  A chain with two or more non-diagonal gates becomes one QK_UC;
+    // any other chain is emitted as it was (lone h / rx / ... keep their cheap special forms, diagonal
+    // gates keep merging into diagonal stages).  Circuits without such a chain keep their gate order.
+    struct Factor { int32_t gate, expr; };
+    std::vector<std::vector<Factor>> comps;
+    {
+        auto single = [](const Item& it) { return it.diag ? (it.kind == TM_P || it.kind == TM_RZ) : it.kind == ST_U1; };
+        std::vector<std::vector<Item>> chain(n);
+        std::vector<Item> out;
+        bool any = false;
+        auto flush_q = [&](int q) {
+            std::vector<Item>& ch = chain[q];
+            int first_nd = -1, last_nd = -1, nd = 0;
+            for (int k = 0; k < (int)ch.size(); ++k)
+                if (!ch[k].diag) { if (first_nd < 0) first_nd = k; last_nd = k; ++nd; }
+            if (nd < 2) {
+                out.insert(out.end(), ch.begin(), ch.end());
+            } else {
+                // the whole chain, diagonal gates at its head and tail included: a composite that is the first
+                // thing on its qubit joins the initial product state, and no diagonal stage is left behind
+                any = true;
+                std::vector<Factor> fs;
+                for (const Item& g : ch)
+                    fs.push_back(Factor{g.diag ? (g.kind == TM_P ? (int32_t)QK_P : (int32_t)QK_RZ) : g.gate, g.expr});
+                out.push_back(Item{false, ST_U1, QK_UC, q, -1, (int32_t)comps.size()});
+                comps.push_back(std::move(fs));
+            }
+            (void)first_nd; (void)last_nd;
+            ch.clear();
+        };
+        for (const Item& it : items) {
+            if (single(it)) { chain[it.q0].push_back(it); continue; }
+            flush_q(it.q0);
+            if (it.q1 >= 0) flush_q(it.q1);
+            out.push_back(it);
+        }
+        for (int q = 0; q < n; ++q) flush_q(q);
+        if (any) items.swap(out);
+        else comps.clear();
+    }
+
     // A single-qubit gate that is the very first operation on its qubit acts on |0> and commutes
     // with everything before it: all of those are hoisted to the start of the circuit, where they
     // turn |0...0> into a product state the first pass writes directly (ST_INIT) -- no sweeps and
@@ -123,6 +172,24 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     }
     flush();
 
+    {
+        int n_u1 = 0, n_uc = 0, n_cx = 0, n_ecr = 0, n_diag = 0, n_terms = 0, n_fact = 0;
+        for (const Proto& p : seq) {
+            if (p.diag) { ++n_diag; n_terms += (int)p.terms.size(); }
+            else if (p.nd.kind == ST_U1) { if (p.nd.gate == QK_UC) ++n_uc; else ++n_u1; }
+            else if (p.nd.kind == ST_CX) ++n_cx;
+            else ++n_ecr;
+        }
+        for (const auto& f : comps) n_fact += (int)f.size();
+        int init_uc = 0;
+        for (const Item& g : inits) init_uc += g.gate == QK_UC;
+        c.plan_summary = "gates " + std::to_string(c.n_gates) + ": product-state gates " + std::to_string(inits.size()) +
+                         " (" + std::to_string(init_uc) + " composite), then u1 " + std::to_string(n_u1) + ", composite u1 " +
+                         std::to_string(n_uc) + ", cx " + std::to_string(n_cx) + ", ecr " + std::to_string(n_ecr) +
+                         ", diagonal stages " + std::to_string(n_diag) + " with " + std::to_string(n_terms) + " terms; composites " +
+                         std::to_string(comps.size()) + " over " + std::to_string(n_fact) + " factors";
+    }
+
     // ---- 2b. the wave-resident program (up to 10 qubits: the state lives in one wavefront's registers) ----
     c.wave_blob.clear();
     if (n <= kWaveMaxQubits && n_expr <= kWaveMaxExprs) {
@@ -132,9 +199,18 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         std::vector<WaveExpr> wexprs(n_expr);
         for (int e = 0; e < n_expr; ++e) wexprs[e] = WaveExpr{expr_off[e], expr_off[e + 1] - expr_off[e], 1.0};
         auto half = [&](int e) { if (e >= 0) wexprs[e].scale = 0.5; };
+        std::vector<WaveComp> wcomps;
+        std::vector<WaveFactor> wfacts;
+        for (const auto& fs : comps) {
+            wcomps.push_back(WaveComp{(int32_t)wfacts.size(), (int32_t)fs.size()});
+            for (const Factor& f : fs) {
+                wfacts.push_back(WaveFactor{f.gate, f.expr});
+                if (f.gate != QK_P) half(f.expr);
+            }
+        }
         for (const Item& g : inits) {
             winit[g.q0] = WaveInit{g.gate, g.expr};
-            half(g.expr);
+            if (g.gate != QK_UC) half(g.expr);
         }
         for (const Proto& p : seq) {
             if (p.diag) {
@@ -145,7 +221,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 }
             } else if (p.nd.kind == ST_U1) {
                 wops.push_back(WaveOp{WV_U1, p.nd.q0, p.nd.gate, p.nd.expr});
-                half(p.nd.expr);
+                if (p.nd.gate != QK_UC) half(p.nd.expr);
             } else {
                 wops.push_back(WaveOp{p.nd.kind == ST_CX ? WV_CX : WV_ECR, p.nd.q0, p.nd.q1, -1});
             }
@@ -159,6 +235,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         H.n_exprs = n_expr;
         H.n_prog = (int32_t)c.prog.size();
         H.n_consts = (int32_t)c.consts.size();
+        H.n_comps = (int32_t)wcomps.size();
         H.spw = n_expr > 0 ? std::max(1, 64 / n_expr) : 64;
         size_t off = sizeof(WaveHeader);
         H.off_ops = (int32_t)off;      off = pad8(off + wops.size() * sizeof(WaveOp));
@@ -167,6 +244,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         H.off_exprs = (int32_t)off;    off = pad8(off + wexprs.size() * sizeof(WaveExpr));
         H.off_prog = (int32_t)off;     off = pad8(off + c.prog.size() * sizeof(qk_instr));
         H.off_consts = (int32_t)off;   off = pad8(off + c.consts.size() * sizeof(double));
+        H.off_comps = (int32_t)off;    off = pad8(off + wcomps.size() * sizeof(WaveComp));
+        H.off_facts = (int32_t)off;    off = pad8(off + wfacts.size() * sizeof(WaveFactor));
         H.bytes = (int32_t)off;
         c.wave_blob.assign(off / 8, 0);
         char* base = (char*)c.wave_blob.data();
@@ -177,6 +256,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         if (!wexprs.empty()) std::memcpy(base + H.off_exprs, wexprs.data(), wexprs.size() * sizeof(WaveExpr));
         if (!c.prog.empty()) std::memcpy(base + H.off_prog, c.prog.data(), c.prog.size() * sizeof(qk_instr));
         if (!c.consts.empty()) std::memcpy(base + H.off_consts, c.consts.data(), c.consts.size() * sizeof(double));
+        if (!wcomps.empty()) std::memcpy(base + H.off_comps, wcomps.data(), wcomps.size() * sizeof(WaveComp));
+        if (!wfacts.empty()) std::memcpy(base + H.off_facts, wfacts.data(), wfacts.size() * sizeof(WaveFactor));
         c.wave_spw = H.spw;
     }
 
@@ -191,8 +272,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             for (int q = 0; q < (n <= Lcap ? n : n_fixed); ++q) d.S.push_back(q);
             drafts.push_back(d);
         };
+        auto mats_of = [&](const Item& g) { return g.gate == QK_UC ? 1 + (int)comps[g.expr].size() : 1; };
         new_draft();
-        drafts.back().n_mat = (int)inits.size();
+        for (const Item& g : inits) drafts.back().n_mat += mats_of(g);
         for (int s = 0; s < (int)seq.size(); ++s) {
             const Proto& p = seq[s];
             std::vector<int> need;
@@ -200,7 +282,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             if (p.diag) {
                 add_term = (int)p.terms.size();
             } else {
-                if (p.nd.kind == ST_U1) { need = {p.nd.q0}; add_mat = 1; }
+                if (p.nd.kind == ST_U1) { need = {p.nd.q0}; add_mat = mats_of(p.nd); }
                 if (p.nd.kind == ST_CX) need = {p.nd.q1};
                 if (p.nd.kind == ST_ECR) need = {p.nd.q0, p.nd.q1};
             }
@@ -243,6 +325,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     c.terms.clear();
     c.exprs.clear();
     c.mats.clear();
+    c.comps.clear();
+    c.facts.clear();
     for (size_t pi = 0; pi < drafts.size(); ++pi) {
         Draft& d = drafts[pi];
         // fill the local set with the lowest unused qubits
@@ -279,6 +363,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         ps.expr_off = (int)c.exprs.size();
         ps.mat_off = (int)c.mats.size();
         ps.term_off = (int)c.terms.size();
+        ps.comp_off = (int)c.comps.size();
+        ps.fact_off = (int)c.facts.size();
         auto add_expr = [&](int e, double scale, int dst, int gate = 0) {
             c.exprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale, dst, gate});
         };
@@ -288,12 +374,32 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 if (qubit_mask >> q & 1u) m |= 1u << virt[q];
             return m;
         };
-        if (pi == 0) {
-            for (const Item& g : inits) {
-                active |= 1u << g.q0;
+        // the matrix of a single-qubit item: its own slot, and for a composite one slot per factor before it
+        auto add_matrix = [&](const Item& g) {
+            if (g.gate != QK_UC) {
                 c.mats.push_back(DevMat{g.gate, 0});
                 const int mi = (int)c.mats.size() - 1 - ps.mat_off;
                 if (g.expr >= 0) add_expr(g.expr, 0.5, ~mi, g.gate);
+                return mi;
+            }
+            DevComp dc{};
+            dc.first = (int)c.facts.size() - ps.fact_off;
+            dc.count = (int)comps[g.expr].size();
+            for (const Factor& f : comps[g.expr]) {
+                c.mats.push_back(DevMat{f.gate, 0});
+                const int fi = (int)c.mats.size() - 1 - ps.mat_off;
+                if (f.expr >= 0) add_expr(f.expr, f.gate == QK_P ? 1.0 : 0.5, ~fi, f.gate);
+                c.facts.push_back(fi);
+            }
+            c.mats.push_back(DevMat{QK_UC, 0});
+            dc.dst = (int)c.mats.size() - 1 - ps.mat_off;
+            c.comps.push_back(dc);
+            return dc.dst;
+        };
+        if (pi == 0) {
+            for (const Item& g : inits) {
+                active |= 1u << g.q0;
+                const int mi = add_matrix(g);
                 DevStage st{};
                 st.kind = ST_INIT;
                 st.va = virt[g.q0];
@@ -352,9 +458,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             const Item& g = p.nd;
             if (g.kind == ST_U1) {
                 active |= 1u << g.q0;
-                c.mats.push_back(DevMat{g.gate, 0});
-                const int mi = (int)c.mats.size() - 1 - ps.mat_off;
-                if (g.expr >= 0) add_expr(g.expr, 0.5, ~mi, g.gate);
+                const int mi = add_matrix(g);
                 const int v = virt[g.q0];
                 // fuse with the previous stage if that is a U1 group in this pass without this qubit
                 bool fused = false;
@@ -398,6 +502,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         ps.n_expr = (int)c.exprs.size() - ps.expr_off;
         ps.n_term = (int)c.terms.size() - ps.term_off;
         ps.n_mat = (int)c.mats.size() - ps.mat_off;
+        ps.n_comp = (int)c.comps.size() - ps.comp_off;
         c.passes.push_back(ps);
     }
     return QK_OK;

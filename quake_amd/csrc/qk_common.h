@@ -78,8 +78,19 @@ struct DevExpr {      // one gate angle evaluated per sample
     int32_t gate;         // qk_gate of that matrix (rx / ry), 0 for terms
 };
 
-struct DevMat {       // a 2x2 matrix: constant for h / x / sx, filled from its angle for rx / ry
-    int32_t gate;     // qk_gate
+struct DevMat {       // a 2x2 matrix: constant for h / x / sx, filled from its angle for rx / ry / rz / p,
+    int32_t gate;     // qk_gate, or QK_UC: the product of other matrices of the pass (DevComp)
+    int32_t pad;
+};
+
+// Runs of single-qubit gates on one qubit with nothing two-qubit in between (the bulk of a GA genome circuit:
+// reference genetic_v3.py:326-448 draws one gate per qubit and layer) are applied as ONE 2x2 matrix, the product
+// of the run, formed per sample from the factors' matrices.  QK_UC marks such a matrix; it is not a gate code
+// of the public header.
+constexpr int32_t QK_UC = 64;
+struct DevComp {
+    int32_t dst;           // pass-local matrix that takes the product
+    int32_t first, count;  // its factors: pass-local matrix indices facts[first .. first + count), in order of application
     int32_t pad;
 };
 
@@ -107,6 +118,8 @@ struct Pass {
     int expr_off = 0, n_expr = 0;
     int term_off = 0, n_term = 0;
     int mat_off = 0, n_mat = 0;
+    int comp_off = 0, n_comp = 0;   // composite matrices (DevComp) of the pass; their factor lists index c.facts from fact_off
+    int fact_off = 0;
     // bit-deposit runs: physical = OR_r ((virtual & mask[r]) << shift[r])
     int nruns = 0;
     uint32_t run_mask[kMaxRuns] = {0};
@@ -134,12 +147,15 @@ struct qk_circuit {
     int n_qubits = 0;
     int n_params = 0;
     int n_gates = 0;                 // gates that touch the state (after dropping id)
+    std::string plan_summary;        // what the planner made of them (development hook qk_circuit_plan_summary)
     std::vector<qk::Pass> passes;
     // host copies (uploaded lazily per device)
     std::vector<qk::DevStage> stages;
     std::vector<qk::DevTerm> terms;
     std::vector<qk::DevExpr> exprs;
     std::vector<qk::DevMat> mats;
+    std::vector<qk::DevComp> comps;
+    std::vector<int32_t> facts;
     std::vector<qk_instr> prog;
     std::vector<double> consts;
     // wave-resident program (n_qubits <= 10): one position-independent blob, empty when the circuit does not qualify
@@ -154,6 +170,8 @@ struct qk_circuit {
     qk::DevTerm* d_terms = nullptr;
     qk::DevExpr* d_exprs = nullptr;
     qk::DevMat* d_mats = nullptr;
+    qk::DevComp* d_comps = nullptr;
+    int32_t* d_facts = nullptr;
     qk_instr* d_prog = nullptr;
     double* d_consts = nullptr;
 };

@@ -34,6 +34,9 @@ struct SimArgs {
     const DevTerm* terms;
     const DevExpr* exprs;
     const DevMat* mats;
+    const DevComp* comps;    // composite matrices of the pass and their factor lists (pass-local matrix indices)
+    const int32_t* facts;
+    int n_comp;
     const qk_instr* prog;
     const double* consts;
     int n_stage, n_expr, n_mat, n_term;
@@ -231,11 +234,17 @@ __device__ __forceinline__ void run_angle_programs(ExprPtr exprs, ProgPtr prog, 
         if (ex.dst >= 0) {
             rt[ex.dst].c = cn;
             rt[ex.dst].s = sn;
-        } else {  // rx / ry from cos, sin of theta/2
+        } else {  // rx / ry / rz from cos, sin of theta/2, p from those of lambda (rz, p: only as factors of a composite)
             const int m = ~ex.dst;
             if (ex.gate == QK_RX) {
                 mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(0, -sn);
                 mat[4 * m + 2] = make_double2(0, -sn); mat[4 * m + 3] = make_double2(cn, 0);
+            } else if (ex.gate == QK_RZ) {
+                mat[4 * m + 0] = make_double2(cn, -sn); mat[4 * m + 1] = make_double2(0, 0);
+                mat[4 * m + 2] = make_double2(0, 0); mat[4 * m + 3] = make_double2(cn, sn);
+            } else if (ex.gate == QK_P) {
+                mat[4 * m + 0] = make_double2(1, 0); mat[4 * m + 1] = make_double2(0, 0);
+                mat[4 * m + 2] = make_double2(0, 0); mat[4 * m + 3] = make_double2(cn, sn);
             } else {
                 mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(-sn, 0);
                 mat[4 * m + 2] = make_double2(sn, 0); mat[4 * m + 3] = make_double2(cn, 0);
@@ -363,6 +372,22 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             if (a.staged) run_angle_programs(s_expr, s_prog, s_const, xrow, a.n_expr, rt, mat, tid, T);
             else run_angle_programs(a.exprs, a.prog, a.consts, xrow, a.n_expr, rt, mat, tid, T);
             angles_of = sample;
+            if (a.n_comp) {     // runs of single-qubit gates on one qubit: one thread multiplies a run's factors
+                __syncthreads();
+                for (int k = tid; k < a.n_comp; k += T) {
+                    const DevComp cc = a.comps[k];
+                    const int32_t* f = a.facts + cc.first;
+                    double2 m0 = mat[4 * f[0]], m1 = mat[4 * f[0] + 1], m2 = mat[4 * f[0] + 2], m3 = mat[4 * f[0] + 3];
+                    for (int j = 1; j < cc.count; ++j) {     // M <- G M
+                        const double2* g = mat + 4 * f[j];
+                        const double2 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                        const double2 n0 = cfma(g1, m2, cmul(g0, m0)), n1 = cfma(g1, m3, cmul(g0, m1));
+                        const double2 n2 = cfma(g3, m2, cmul(g2, m0)), n3 = cfma(g3, m3, cmul(g2, m1));
+                        m0 = n0; m1 = n1; m2 = n2; m3 = n3;
+                    }
+                    mat[4 * cc.dst] = m0; mat[4 * cc.dst + 1] = m1; mat[4 * cc.dst + 2] = m2; mat[4 * cc.dst + 3] = m3;
+                }
+            }
             if (hoist) {
                 __syncthreads();
                 const DevStage st = a.stages[a.n_init];
@@ -649,6 +674,8 @@ int upload_circuit(qk_circuit& c) {
     QK_HIP(up(c.d_terms, c.terms));
     QK_HIP(up(c.d_exprs, c.exprs));
     QK_HIP(up(c.d_mats, c.mats));
+    QK_HIP(up(c.d_comps, c.comps));
+    QK_HIP(up(c.d_facts, c.facts));
     QK_HIP(up(c.d_prog, c.prog));
     QK_HIP(up(c.d_consts, c.consts));
     if (!c.wave_blob.empty()) {
@@ -663,6 +690,8 @@ void free_circuit_device(qk_circuit& c) {
     if (c.device < 0) return;
     (void)hipFree(c.d_stages); (void)hipFree(c.d_terms); (void)hipFree(c.d_exprs);
     (void)hipFree(c.d_mats); (void)hipFree(c.d_prog); (void)hipFree(c.d_consts);
+    (void)hipFree(c.d_comps); (void)hipFree(c.d_facts);
+    c.d_comps = nullptr; c.d_facts = nullptr;
     if (c.d_wave) (void)hipFree(c.d_wave);
     c.d_wave = nullptr;
     c.d_stages = nullptr; c.d_terms = nullptr; c.d_exprs = nullptr;
@@ -722,6 +751,9 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.terms = c.d_terms + ps.term_off;
         a.exprs = c.d_exprs + ps.expr_off;
         a.mats = c.d_mats + ps.mat_off;
+        a.comps = c.d_comps + ps.comp_off;
+        a.facts = c.d_facts + ps.fact_off;
+        a.n_comp = ps.n_comp;
         a.prog = c.d_prog;
         a.consts = c.d_consts;
         a.n_stage = ps.n_stage;

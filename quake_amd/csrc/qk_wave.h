@@ -14,8 +14,8 @@ enum WaveOpKind : int32_t { WV_U1 = 0, WV_CX = 1, WV_ECR = 2, WV_DIAG = 3 };
 struct WaveOp {       // 16 bytes
     int32_t kind;     // WaveOpKind
     int32_t a;        // U1: qubit            CX: control   ECR: q0   DIAG: first term
-    int32_t b;        // U1: qk_gate          CX: target    ECR: q1   DIAG: number of terms
-    int32_t c;        // U1: angle index of rx / ry, else -1
+    int32_t b;        // U1: qk_gate or QK_UC CX: target    ECR: q1   DIAG: number of terms
+    int32_t c;        // U1: angle index of rx / ry, composite index of QK_UC, else -1
 };
 
 struct WaveTerm {     // one factor of a diagonal run
@@ -25,8 +25,17 @@ struct WaveTerm {     // one factor of a diagonal run
 };
 
 struct WaveInit {     // first gate on a qubit, folded into the initial product state
-    int32_t gate;     // qk_gate, or -1: the qubit starts in |0>
-    int32_t expr;     // angle index of rx / ry, else -1
+    int32_t gate;     // qk_gate, QK_UC, or -1: the qubit starts in |0>
+    int32_t expr;     // angle index of rx / ry, composite index of QK_UC, else -1
+};
+
+struct WaveComp {     // a run of single-qubit gates on one qubit, applied as the product of its factors
+    int32_t first, count;   // factors [first, first + count), in order of application
+};
+
+struct WaveFactor {
+    int32_t gate;     // qk_gate: h x sx rx ry rz p
+    int32_t expr;     // angle index of a parametric factor, else -1
 };
 
 struct WaveExpr {
@@ -34,11 +43,12 @@ struct WaveExpr {
     double scale;         // 0.5 for rx / ry / rz (half angle), 1 for p and the ZZ phase
 };
 
-struct WaveHeader {   // 64 bytes, at offset 0 of the blob; off_* are byte offsets from the blob's start
+struct WaveHeader {   // 80 bytes, at offset 0 of the blob; off_* are byte offsets from the blob's start
     int32_t n_qubits, n_params, n_ops, n_terms, n_exprs, n_prog, n_consts;
     int32_t spw;      // samples whose angles one pass of the wave evaluates together: max(1, 64 / n_exprs)
     int32_t off_ops, off_terms, off_init, off_exprs, off_prog, off_consts;
-    int32_t bytes, pad;
+    int32_t bytes, n_comps;
+    int32_t off_comps, off_facts, pad0, pad1;
 };
 
 }  // namespace qk

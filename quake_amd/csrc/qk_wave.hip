@@ -114,6 +114,7 @@ __device__ __forceinline__ void first_column(int gate, v2d cs, v2d& u0, v2d& u1)
     const double r = 0.70710678118654752440;
     u0 = (v2d){1.0, 0.0};
     u1 = (v2d){0.0, 0.0};
+    if (gate == QK_UC) return;     // composite: the caller takes the column from the sample's matrix table
     if (gate == QK_H) { u0 = (v2d){r, 0.0}; u1 = (v2d){r, 0.0}; }
     else if (gate == QK_X) { u0 = (v2d){0.0, 0.0}; u1 = (v2d){1.0, 0.0}; }
     else if (gate == QK_SX) { u0 = (v2d){0.5, 0.5}; u1 = (v2d){0.5, -0.5}; }
@@ -182,6 +183,59 @@ __device__ __forceinline__ void u1_gate(v2d (&amp)[NREG], int q, v2d cs, int lan
             }
         });
     }
+}
+
+// a general 2x2 matrix (the product of a run of single-qubit gates: QK_UC), entries m[0..3] = m00 m01 m10 m11
+template <int NREG>
+__device__ __forceinline__ void u1_matrix(v2d (&amp)[NREG], int q, const double2* m, int lane) {
+    const v2d m00 = (v2d){m[0].x, m[0].y}, m01 = (v2d){m[1].x, m[1].y};
+    const v2d m10 = (v2d){m[2].x, m[2].y}, m11 = (v2d){m[3].x, m[3].y};
+    if (q < 6) {
+        const bool hi = (lane >> q) & 1;
+        const v2d ca = hi ? m11 : m00, cp = hi ? m10 : m01;    // new = ca * own + cp * partner
+        with_lane_qubit(q, lane, [&](auto X) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                const v2d a = amp[r];
+                const v2d p = X(a);
+                const v2d t = cmul(ca, a);
+                amp[r] = (v2d){fma(cp.x, p.x, fma(-cp.y, p.y, t.x)), fma(cp.x, p.y, fma(cp.y, p.x, t.y))};
+            }
+        });
+    } else {
+        with_reg_qubit<NREG>(q, [&](auto TT) __attribute__((always_inline)) {
+            constexpr int T = decltype(TT)::value;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                if (r & (1 << T)) continue;
+                const v2d a0 = amp[r], a1 = amp[r | (1 << T)];
+                const v2d t0 = cmul(m00, a0), t1 = cmul(m10, a0);
+                amp[r] = (v2d){fma(m01.x, a1.x, fma(-m01.y, a1.y, t0.x)), fma(m01.x, a1.y, fma(m01.y, a1.x, t0.y))};
+                amp[r | (1 << T)] = (v2d){fma(m11.x, a1.x, fma(-m11.y, a1.y, t1.x)), fma(m11.x, a1.y, fma(m11.y, a1.x, t1.y))};
+            }
+        });
+    }
+}
+
+// the matrix of one factor of a composite: h x sx constant, rx ry rz from (cos, sin) of theta / 2, p from those of lambda
+__device__ __forceinline__ void factor_matrix(int gate, double c, double s, double2& g0, double2& g1, double2& g2, double2& g3) {
+    const double r = 0.70710678118654752440;
+    const double2 z = make_double2(0.0, 0.0);
+    g0 = make_double2(1.0, 0.0); g1 = z; g2 = z; g3 = make_double2(1.0, 0.0);
+    if (gate == QK_H) { g0 = make_double2(r, 0); g1 = make_double2(r, 0); g2 = make_double2(r, 0); g3 = make_double2(-r, 0); }
+    else if (gate == QK_X) { g0 = z; g1 = make_double2(1, 0); g2 = make_double2(1, 0); g3 = z; }
+    else if (gate == QK_SX) { g0 = make_double2(0.5, 0.5); g1 = make_double2(0.5, -0.5); g2 = make_double2(0.5, -0.5); g3 = make_double2(0.5, 0.5); }
+    else if (gate == QK_RX) { g0 = make_double2(c, 0); g1 = make_double2(0, -s); g2 = make_double2(0, -s); g3 = make_double2(c, 0); }
+    else if (gate == QK_RY) { g0 = make_double2(c, 0); g1 = make_double2(-s, 0); g2 = make_double2(s, 0); g3 = make_double2(c, 0); }
+    else if (gate == QK_RZ) { g0 = make_double2(c, -s); g3 = make_double2(c, s); }
+    else if (gate == QK_P) { g3 = make_double2(c, s); }
+}
+__device__ __forceinline__ double2 cmul2(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ double2 cfma2(double2 a, double2 b, double2 c) {
+    return make_double2(fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y)));
 }
 
 template <int NREG>
@@ -395,19 +449,20 @@ __device__ __forceinline__ double2 eval_angle(const WaveExpr ex, const qk_instr*
 namespace {
 // product state over the register qubits, one qubit per template step (static register indices)
 template <int NREG, int T>
-__device__ __forceinline__ void init_reg_qubits(v2d (&amp)[NREG], const WaveInit* init, const double2* cs, int n) {
+__device__ __forceinline__ void init_reg_qubits(v2d (&amp)[NREG], const WaveInit* init, const double2* cs, const double2* um, int n) {
     if constexpr ((1 << T) < NREG) {
         v2d u0 = (v2d){1.0, 0.0}, u1 = (v2d){0.0, 0.0};
         if (6 + T < n) {
             const int gate = uni(init[6 + T].gate), expr = uni(init[6 + T].expr);
-            first_column(gate, expr >= 0 ? angle_cs(cs, expr) : (v2d){1.0, 0.0}, u0, u1);
+            first_column(gate, (expr >= 0 && gate != QK_UC) ? angle_cs(cs, expr) : (v2d){1.0, 0.0}, u0, u1);
+            if (gate == QK_UC) { u0 = (v2d){um[4 * expr].x, um[4 * expr].y}; u1 = (v2d){um[4 * expr + 2].x, um[4 * expr + 2].y}; }
         }
 #pragma unroll
         for (int r = 0; r < (1 << T); ++r) {
             amp[r | (1 << T)] = cmul(amp[r], u1);
             amp[r] = cmul(amp[r], u0);
         }
-        init_reg_qubits<NREG, T + 1>(amp, init, cs, n);
+        init_reg_qubits<NREG, T + 1>(amp, init, cs, um, n);
     }
 }
 }  // namespace
@@ -450,7 +505,10 @@ __global__ void __launch_bounds__(64, NREG >= 16 ? 2 : (NREG >= 8 ? 3 : 4)) wave
         const WaveExpr* exprs = (const WaveExpr*)(blob + H.off_exprs);
         const qk_instr* prog = (const qk_instr*)(blob + H.off_prog);
         const double* consts = (const double*)(blob + H.off_consts);
-        const int n = uni(H.n_qubits), ne = uni(H.n_exprs), n_ops = uni(H.n_ops), spw = uni(H.spw);
+        const WaveComp* comps = (const WaveComp*)(blob + H.off_comps);
+        const WaveFactor* facts = (const WaveFactor*)(blob + H.off_facts);
+        const int n = uni(H.n_qubits), ne = uni(H.n_exprs), n_ops = uni(H.n_ops), spw = uni(H.spw), nc = uni(H.n_comps);
+        double2* const um_lds = cs_lds + spw * ne;     // [sample of the unit][composite][4]: after the (cos, sin) table
         const int64_t s0 = (u - J.unit_begin) * spw;
         const int cnt = uni((int)(J.N - s0 < spw ? J.N - s0 : spw));
 
@@ -460,9 +518,32 @@ __global__ void __launch_bounds__(64, NREG >= 16 ? 2 : (NREG >= 8 ? 3 : 4)) wave
             cs_lds[idx] = eval_angle(exprs[e], prog, consts, J.X + (s0 + sub) * J.ldx);
         }
         __syncthreads();
+        // ---- composite matrices: one lane per (sample, run of single-qubit gates) multiplies the run's factors ----
+        if (nc > 0) {
+            for (int idx = lane; idx < cnt * nc; idx += 64) {
+                const int sub = idx / nc, k = idx - sub * nc;
+                const WaveComp cc = comps[k];
+                const double2* cs = cs_lds + sub * ne;
+                // (named values, not arrays: an array indexed inside this loop would live in scratch memory)
+                double2 m0 = make_double2(1.0, 0.0), m1 = make_double2(0.0, 0.0), m2 = m1, m3 = m0;
+                for (int j = 0; j < cc.count; ++j) {      // M <- G M, starting from the identity
+                    const WaveFactor f = facts[cc.first + j];
+                    const double2 a = f.expr >= 0 ? cs[f.expr] : make_double2(1.0, 0.0);
+                    double2 g0, g1, g2, g3;
+                    factor_matrix(f.gate, a.x, a.y, g0, g1, g2, g3);
+                    const double2 n0 = cfma2(g1, m2, cmul2(g0, m0)), n1 = cfma2(g1, m3, cmul2(g0, m1));
+                    const double2 n2 = cfma2(g3, m2, cmul2(g2, m0)), n3 = cfma2(g3, m3, cmul2(g2, m1));
+                    m0 = n0; m1 = n1; m2 = n2; m3 = n3;
+                }
+                double2* o = um_lds + (sub * nc + k) * 4;
+                o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m3;
+            }
+            __syncthreads();
+        }
 
         for (int sub = 0; sub < cnt; ++sub) {
             const double2* cs = cs_lds + sub * ne;
+            const double2* um = um_lds + sub * nc * 4;
             const int64_t sample = s0 + sub;
             v2d amp[NREG];
             double scale = 1.0;
@@ -472,11 +553,12 @@ __global__ void __launch_bounds__(64, NREG >= 16 ? 2 : (NREG >= 8 ? 3 : 4)) wave
                 for (int q = 0; q < n && q < 6; ++q) {
                     const int gate = uni(init[q].gate), expr = uni(init[q].expr);
                     v2d u0, u1;
-                    first_column(gate, expr >= 0 ? angle_cs(cs, expr) : (v2d){1.0, 0.0}, u0, u1);
+                    first_column(gate, (expr >= 0 && gate != QK_UC) ? angle_cs(cs, expr) : (v2d){1.0, 0.0}, u0, u1);
+                    if (gate == QK_UC) { u0 = (v2d){um[4 * expr].x, um[4 * expr].y}; u1 = (v2d){um[4 * expr + 2].x, um[4 * expr + 2].y}; }
                     f = cmul(f, ((lane >> q) & 1) ? u1 : u0);
                 }
                 amp[0] = f;
-                init_reg_qubits<NREG, 0>(amp, init, cs, n);
+                init_reg_qubits<NREG, 0>(amp, init, cs, um, n);
             }
             // ---- gates --------------------------------------------------------------------------------
             WaveOp next_op = ops[0];    // (a circuit without gates still has this slot: the blob is padded)
@@ -490,6 +572,8 @@ __global__ void __launch_bounds__(64, NREG >= 16 ? 2 : (NREG >= 8 ? 3 : 4)) wave
                 op.kind = uni(op.kind); op.a = uni(op.a); op.b = uni(op.b); op.c = uni(op.c);
                 if (op.kind == WV_DIAG) {
                     diag_run<NREG>(amp, terms, op.a, op.b, cs, lane);
+                } else if (op.kind == WV_U1 && op.b == QK_UC) {
+                    u1_matrix<NREG>(amp, op.a, um + 4 * op.c, lane);
                 } else if (op.kind == WV_U1) {
                     if (op.b == QK_H) scale *= 0.70710678118654752440;
                     else if (op.b == QK_SX) scale *= 0.5;
@@ -537,7 +621,7 @@ int wave_nreg_class(int n_qubits) { return n_qubits <= 6 ? 1 : (1 << (n_qubits -
 size_t wave_lds_bytes(const qk_circuit& c) {
     if (c.wave_blob.empty()) return 0;
     const WaveHeader* H = (const WaveHeader*)c.wave_blob.data();
-    return (size_t)16 * std::max(1, H->spw * H->n_exprs);
+    return (size_t)16 * std::max(1, H->spw * (H->n_exprs + 4 * H->n_comps));    // (cos, sin) pairs, then the composite matrices
 }
 
 // All jobs of one call must belong to one register class (the caller groups them).  cs_bytes: the largest

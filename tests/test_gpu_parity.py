@@ -110,6 +110,41 @@ def test_statevectors_random_circuits(n, seed):
     assert np.abs(got - psi_from_compiled(c, X)).max() < TOL_PSI
 
 
+@pytest.mark.parametrize("n,seed", [(1, 0), (3, 1), (7, 2), (10, 3), (11, 4), (12, 5), (14, 6)])
+def test_statevectors_single_qubit_runs(n, seed):
+    """Long runs of single-qubit gates on one qubit between rare two-qubit gates (the shape of a GA genome
+    circuit, reference genetic_v3.py:326-448): the planner multiplies each run into one 2x2 matrix per sample.
+    Runs with rz / p inside, at their head and at their tail, first on a qubit (product state) and after a cx,
+    on the wave-resident simulator (n <= 10) and the LDS one (one pass and several)."""
+    rng = np.random.default_rng(100 + seed)
+    F = 4
+    x = qc.ParameterVector("x", F)
+    c = qc.QuantumCircuit(n)
+    for k in range(F):          # every feature is used at least once
+        c.ry(x[k], k % n)
+    for layer in range(10):
+        for q in range(n):
+            g = int(rng.integers(0, 8))
+            a = x[int(rng.integers(0, F))] * float(rng.uniform(0.5, 2.0))
+            if g == 0: c.h(q)
+            elif g == 1: c.sx(q)
+            elif g == 2: c.x(q)
+            elif g == 3: c.rx(a, q)
+            elif g == 4: c.ry(a, q)
+            elif g == 5: c.rz(a, q)
+            elif g == 6: c.p(a, q)
+            else: c.id(q)
+        if n > 1 and layer % 3 == 2:
+            q, r = (int(v) for v in rng.choice(n, size=2, replace=False))
+            if layer % 2: c.cx(q, r)
+            else: c.ecr(q, r)
+    X = synth_X(3, F, "scaled", 900 + n)
+    got = HipFidelityKernel(c).statevectors(X)
+    ref = psi_from_compiled(c, X)
+    assert np.abs(got - ref).max() < TOL_PSI
+    assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() < 1e-13
+
+
 @pytest.mark.parametrize("N,M", [(1, 1), (5, 3), (130, 57), (257, 129)])
 def test_evaluate_symmetric_and_cross(N, M):
     n = 6
