@@ -61,14 +61,15 @@ struct LaneXor {
     __device__ __forceinline__ double operator()(double v) const {
         // The empty asm statements keep the double <-> integer reinterpretation of the cross-lane builtins in
         // registers: folded into the loads and stores of the amplitude array it leaves that array in scratch.
-        asm volatile("" : "+v"(v));
         double out;
-        if constexpr (KIND == 0) out = __builtin_amdgcn_update_dpp(0.0, v, 0xB1, 0xF, 0xF, false);
-        else if constexpr (KIND == 1) out = __builtin_amdgcn_update_dpp(0.0, v, 0x4E, 0xF, 0xF, false);
+        // every lane has a valid source under these controls, so the "old" operand never shows: bound_ctrl with
+        // an old value of 0 lets the instruction stand alone (no register to clear first)
+        if constexpr (KIND == 0) out = __builtin_amdgcn_update_dpp(0.0, v, 0xB1, 0xF, 0xF, true);
+        else if constexpr (KIND == 1) out = __builtin_amdgcn_update_dpp(0.0, v, 0x4E, 0xF, 0xF, true);
         else if constexpr (KIND == 2) {   // lanes with bit 2 clear (banks 0, 2) take lane + 4, the others lane - 4
-            const double t = __builtin_amdgcn_update_dpp(0.0, v, 0x12C, 0xF, 0x5, false);
+            const double t = __builtin_amdgcn_update_dpp(0.0, v, 0x12C, 0xF, 0x5, true);
             out = __builtin_amdgcn_update_dpp(t, v, 0x124, 0xF, 0xA, false);
-        } else if constexpr (KIND == 3) out = __builtin_amdgcn_update_dpp(0.0, v, 0x128, 0xF, 0xF, false);
+        } else if constexpr (KIND == 3) out = __builtin_amdgcn_update_dpp(0.0, v, 0x128, 0xF, 0xF, true);
         else {
             const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
             const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
