@@ -12,12 +12,16 @@
 //       VALU add per fragment).  Same result to ~1e-16; 25 % fewer matrix-core cycles.
 // The algorithmic count stays 8 real flops per amplitude and entry.
 //
-// The shipped kernel (gram_dma_kernel, 64 x 64 block tiles, four waves, two workgroups per CU): A and B tiles
-// go HBM/L2 -> LDS directly with global_load_lds (no staging registers), double buffered, one barrier per 16
-// amplitudes.  The LDS image is row-major with 256-byte rows; the DMA writes linearly, so the bank swizzle sits
-// on the SOURCE address (slot s of row r holds amplitude s ^ (r & 15)) and the b128 fragment reads are conflict
-// free.  The register-staged kernel below it (gram_kernel, k-major LDS image with one element of padding per
-// row) serves circuits under 4 qubits, where a 16-amplitude k-tile does not exist, and A/B runs.
+// The shipped kernels (gram_ring_kernel<3> for rows of up to 1024 amplitudes, gram_ring_kernel<5> above; 64 x 64
+// block tiles, four waves): A and B tiles go HBM/L2 -> LDS directly with global_load_lds (no staging registers)
+// in stages of 8 amplitudes through a ring of 3 or 5 buffers, the barrier of a stage waiting for the next stage
+// only (partial vmcnt), and the k-loop holds no vector-ALU instruction beside the four fragment sums of the
+// 3-multiplication product -- the FP64 MFMA and the FP64 vector ALU share their multipliers, every other VALU
+// instruction there is lost matrix time (profiles/r02_gram_ablation.md).  gram_dma_kernel below
+// (k-tiles of 16 amplitudes, double buffered, 256-byte LDS rows with slot s of row r holding amplitude
+// s ^ (r & 15)) was the round-1 kernel: it serves rows beyond 2^22 amplitudes and A/B runs, gram_lean_kernel is
+// its geometry with the stripped loop, and the register-staged gram_kernel (k-major LDS image with one element
+// of padding per row) serves circuits under 3 qubits.  All of them give the same bits.
 //
 // Tile schedule (gram_locate): the tiles that have to be computed are listed band by band (8 tile rows),
 // column-major inside a band, and cut into groups of 64 consecutive tiles -- an 8 x 8 macro-tile without dead
@@ -123,7 +127,7 @@ __device__ __forceinline__ bool gram_locate(const GramArgs& args, GramJobDev& J,
 // separate library; the results of such a build are wrong on purpose): bit 0 drops the in-loop DMA, bit 1 the
 // in-loop barrier, bit 2 the in-loop fragment reads (and with them the two VALU adds per fragment), bit 3 points
 // every in-loop DMA at k-tile 0 (always an L2 hit), bit 4 drops the VALU adds only, bit 5 all stores of the epilogue, bit 6 its mirror
-// stores (bits 5 and 6 act on every kernel, bits 0-4 on gram_dma_kernel only).
+// stores (bits 5 and 6 act on every kernel, bit 3 on gram_dma_kernel and gram_ring_kernel, the others on gram_dma_kernel only).
 #ifndef QK_GRAM_ABLATE
 #define QK_GRAM_ABLATE 0
 #endif
@@ -823,7 +827,7 @@ gram_ring_kernel(GramArgs args) {
     // any more: branch-free and harmless.
     auto stage = [&](auto s_c, int hh) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value;
-        const uint32_t koff = (uint32_t)min(hh + NST - 1, lastst) * 128u;
+        const uint32_t koff = (QK_GRAM_ABLATE & 8) ? 0u : (uint32_t)min(hh + NST - 1, lastst) * 128u;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             double sa[TM], db[TN];
@@ -1293,8 +1297,6 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
         g_attr_set[vi].done();
     }
     if (QK_GRAM_ABLATE & 128) args.trace = g_trace.load();
-    static const int64_t ld_env = std::getenv("QK_GRAM_LD") ? std::atoll(std::getenv("QK_GRAM_LD")) : 0;   // experiment
-    if (ld_env >= D) args.ld = ld_env;
     V.launch(args, (unsigned)blocks, (hipStream_t)stream);
     QK_HIP(hipGetLastError());
     return QK_OK;

@@ -322,6 +322,46 @@ def test_gram_raw_layout_asymmetric():
         assert (S[0] == -1).all() and (S[:, :2] == -1).all() and (S[N + 1:] == -1).all() and (S[:, N + 2:] == -1).all()
 
 
+def test_gram_kernel_variants_agree_bitwise():
+    """Every Gram kernel sums the amplitudes of an entry in the same order (16 x 16 x 4 MFMA steps in ascending
+    k, three accumulators), so the round-1 kernel, the lean one and both LDS-ring kernels must give the SAME
+    bits -- on ragged edges, cross jobs with the transposed copy, symmetric jobs, one-stage rows (D = 8) and rows
+    whose stage count leaves every remainder of the ring's unrolling."""
+    import ctypes as C
+    import torch
+    from quake_amd import _lib, device as dev
+
+    lib = _lib.load()
+    lib.qk_gram_set_variant.argtypes = [C.c_char_p]
+    lib.qk_gram_set_variant.restype = C.c_int
+    names = ["dma3m_64x64_w4_g64", "lean3m_64x64_w4", "ring3_64x64_w4", "ring5_64x64_w4"]
+    rng = np.random.default_rng(78)
+    try:
+        for (N, M, D) in [(70, 130, 8), (65, 64, 16), (200, 131, 32), (129, 257, 64), (300, 77, 128), (140, 140, 2048)]:
+            A = rng.normal(size=(N, D)) + 1j * rng.normal(size=(N, D))
+            B = rng.normal(size=(M, D)) + 1j * rng.normal(size=(M, D))
+            tA, tB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+            outs = []
+            for nm in names:
+                if D < 16 and not nm.startswith("ring"):
+                    continue       # 16-amplitude k-tiles: these kernels start at D = 16
+                assert lib.qk_gram_set_variant(nm.encode()) == 0
+                K = torch.full((N, M), -1.0, dtype=torch.float64, device="cuda")
+                KT = torch.full((M, N), -1.0, dtype=torch.float64, device="cuda")
+                S = torch.full((N, N), -1.0, dtype=torch.float64, device="cuda")
+                dev.gram_jobs([dict(A=tA, B=tB, K=K, KT=KT), dict(A=tA, B=tA, K=S, symmetric=True)], D)
+                torch.cuda.synchronize()
+                outs.append((nm, K.cpu().numpy(), KT.cpu().numpy(), S.cpu().numpy()))
+            ref = np.abs(A.conj() @ B.T) ** 2
+            assert np.abs(outs[0][1] - ref).max() < 1e-13 * ref.max(), (N, M, D)
+            for nm, K, KT, S in outs:
+                assert np.array_equal(K, outs[0][1]), (nm, N, M, D)
+                assert np.array_equal(KT, K.T), (nm, N, M, D)
+                assert np.array_equal(S, outs[0][3]) and np.array_equal(S, S.T), (nm, N, M, D)
+    finally:
+        lib.qk_gram_set_variant(b"auto")
+
+
 def test_equal_rows_stay_exactly_one():
     """FidelityStatevectorKernel skips pairs whose statevectors compare equal, so those entries are
     exactly 1.0 -- duplicate samples in the symmetric matrix, a test row that is also a train row in

@@ -32,6 +32,7 @@ for r in range(4):   # warm, then the traced launch is the last one
     e0.record(); qdev.gram(psi, None, out=K); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 t = trace.cpu().numpy()
+t = np.concatenate([t, np.arange(len(t), dtype=np.float64)[:, None]], axis=1)    # column 8: the workgroup's block index
 t = t[t[:, 0] > 0]
 if a.out:
     np.save(a.out, t)

@@ -7,6 +7,18 @@ O = "gpurun_out/r02/"
 P = "profiles/r02_"
 with open(P + "bench_default_kernel_trace.md", "w") as f:
     subprocess.check_call([sys.executable, "tools/rocpd_summary.py", O + "kt/kt_results.db"], stdout=f)
+# the Gram launches of the bench run one by one, next to what bench.py measured with HIP events in the same run
+with open(P + "bench_default_kernel_trace.md", "a") as f:
+    c = sqlite3.connect(O + "kt/kt_results.db").cursor()
+    rows = c.execute("select name, duration, grid_x from kernels where name like '%gram%' order by start").fetchall()
+    b = json.loads(open(O + "bench.json").read().strip().splitlines()[-1])
+    full = max(r[2] for r in rows)
+    timed = [r[1] for r in rows if r[2] == full][-b["steps"]:]
+    f.write("\n## Gram launches of this run in launch order (ms)\n\n")
+    f.write(", ".join("%.3f" % (r[1] / 1e6) for r in rows) + "\n\n")
+    f.write("The last %d launches over the full N = %d block are the timed steps: average %.3f ms; `bench.py` in the same run, "
+            "HIP events on the launch stream: ms_per_launch_set = %.3f ms, ms_per_step (wall, barriers included) = %.3f ms.\n"
+            % (len(timed), b["config"]["rows"], sum(timed) / len(timed) / 1e6, b["roofline"]["ms_per_launch_set"], b["ms_per_step"]))
 with open(P + "ga_kernel_trace.md", "w") as f:
     subprocess.check_call([sys.executable, "tools/rocpd_summary.py", O + "ga_kt/kt_results.db"], stdout=f)
 shutil.copy(O + "bench.json", P + "bench_default.json")
