@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -143,6 +144,20 @@ struct WaveJob {
 };
 }  // namespace qk
 
+namespace qk {
+struct DevTables {
+    DevStage* stages = nullptr;
+    DevTerm* terms = nullptr;
+    DevExpr* exprs = nullptr;
+    DevMat* mats = nullptr;
+    DevComp* comps = nullptr;
+    int32_t* facts = nullptr;
+    qk_instr* prog = nullptr;
+    double* consts = nullptr;
+    void* wave = nullptr;      // the wave-resident program, null when the circuit has none
+};
+}  // namespace qk
+
 struct qk_circuit {
     int n_qubits = 0;
     int n_params = 0;
@@ -161,19 +176,12 @@ struct qk_circuit {
     // wave-resident program (n_qubits <= 10): one position-independent blob, empty when the circuit does not qualify
     std::vector<uint64_t> wave_blob;
     int wave_spw = 1;                // samples per unit of work
-    void* d_wave = nullptr;
-    // device copies (uploaded on first use on a device, under `mu`: ctypes releases the GIL, so two host
-    // threads may reach the first call together)
+    // device copies: one set of tables per device, uploaded on first use there and kept until the circuit is
+    // destroyed (under `mu`: ctypes releases the GIL, so two host threads may reach the first call together; a
+    // caller works from a by-value copy of its device's pointers, so another thread on another device cannot
+    // pull them away)
     std::mutex mu;
-    int device = -1;
-    qk::DevStage* d_stages = nullptr;
-    qk::DevTerm* d_terms = nullptr;
-    qk::DevExpr* d_exprs = nullptr;
-    qk::DevMat* d_mats = nullptr;
-    qk::DevComp* d_comps = nullptr;
-    int32_t* d_facts = nullptr;
-    qk_instr* d_prog = nullptr;
-    double* d_consts = nullptr;
+    std::map<int, qk::DevTables> tables;
 };
 
 namespace qk {
@@ -195,6 +203,6 @@ size_t wave_lds_bytes(const qk_circuit& c);   // the (cos, sin) table of one uni
 int launch_wave_jobs(const WaveJob* jobs_host, int n_jobs, const WaveJob* table_dev, int nreg, int64_t total_units,
                      size_t cs_bytes, hipStream_t stream);
 // qk_sim.hip
-int upload_circuit(qk_circuit& c);
+int upload_circuit(qk_circuit& c, DevTables& out);   // the tables of the current device (uploaded on first use)
 void free_circuit_device(qk_circuit& c);
 }  // namespace qk

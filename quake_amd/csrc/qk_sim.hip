@@ -656,12 +656,16 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     }
 }
 
-int upload_circuit(qk_circuit& c) {
+int upload_circuit(qk_circuit& c, DevTables& out) {
     int dev = 0;
     QK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(c.mu);
-    if (c.device == dev) return QK_OK;
-    free_circuit_device(c);
+    auto it = c.tables.find(dev);
+    if (it != c.tables.end()) {
+        out = it->second;
+        return QK_OK;
+    }
+    DevTables t;
     auto up = [&](auto*& dptr, const auto& vec) -> hipError_t {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
         const size_t bytes = std::max<size_t>(vec.size(), 1) * sizeof(T);
@@ -670,33 +674,43 @@ int upload_circuit(qk_circuit& c) {
         if (!vec.empty()) e = hipMemcpy(dptr, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice);
         return e;
     };
-    QK_HIP(up(c.d_stages, c.stages));
-    QK_HIP(up(c.d_terms, c.terms));
-    QK_HIP(up(c.d_exprs, c.exprs));
-    QK_HIP(up(c.d_mats, c.mats));
-    QK_HIP(up(c.d_comps, c.comps));
-    QK_HIP(up(c.d_facts, c.facts));
-    QK_HIP(up(c.d_prog, c.prog));
-    QK_HIP(up(c.d_consts, c.consts));
-    if (!c.wave_blob.empty()) {
-        QK_HIP(hipMalloc(&c.d_wave, c.wave_blob.size() * 8));
-        QK_HIP(hipMemcpy(c.d_wave, c.wave_blob.data(), c.wave_blob.size() * 8, hipMemcpyHostToDevice));
+    auto all = [&]() -> hipError_t {
+        hipError_t e;
+        if ((e = up(t.stages, c.stages)) != hipSuccess) return e;
+        if ((e = up(t.terms, c.terms)) != hipSuccess) return e;
+        if ((e = up(t.exprs, c.exprs)) != hipSuccess) return e;
+        if ((e = up(t.mats, c.mats)) != hipSuccess) return e;
+        if ((e = up(t.comps, c.comps)) != hipSuccess) return e;
+        if ((e = up(t.facts, c.facts)) != hipSuccess) return e;
+        if ((e = up(t.prog, c.prog)) != hipSuccess) return e;
+        if ((e = up(t.consts, c.consts)) != hipSuccess) return e;
+        if (!c.wave_blob.empty()) {
+            if ((e = hipMalloc(&t.wave, c.wave_blob.size() * 8)) != hipSuccess) return e;
+            e = hipMemcpy(t.wave, c.wave_blob.data(), c.wave_blob.size() * 8, hipMemcpyHostToDevice);
+        }
+        return e;
+    };
+    const hipError_t e = all();
+    if (e != hipSuccess) {      // nothing half-built stays behind
+        (void)hipFree(t.stages); (void)hipFree(t.terms); (void)hipFree(t.exprs); (void)hipFree(t.mats);
+        (void)hipFree(t.comps); (void)hipFree(t.facts); (void)hipFree(t.prog); (void)hipFree(t.consts);
+        if (t.wave) (void)hipFree(t.wave);
+        return fail(QK_ERR_HIP, std::string("uploading the circuit tables: ") + hipGetErrorString(e));
     }
-    c.device = dev;
+    c.tables[dev] = t;
+    out = t;
     return QK_OK;
 }
 
 void free_circuit_device(qk_circuit& c) {
-    if (c.device < 0) return;
-    (void)hipFree(c.d_stages); (void)hipFree(c.d_terms); (void)hipFree(c.d_exprs);
-    (void)hipFree(c.d_mats); (void)hipFree(c.d_prog); (void)hipFree(c.d_consts);
-    (void)hipFree(c.d_comps); (void)hipFree(c.d_facts);
-    c.d_comps = nullptr; c.d_facts = nullptr;
-    if (c.d_wave) (void)hipFree(c.d_wave);
-    c.d_wave = nullptr;
-    c.d_stages = nullptr; c.d_terms = nullptr; c.d_exprs = nullptr;
-    c.d_mats = nullptr; c.d_prog = nullptr; c.d_consts = nullptr;
-    c.device = -1;
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (auto& kv : c.tables) {
+        DevTables& t = kv.second;
+        (void)hipFree(t.stages); (void)hipFree(t.terms); (void)hipFree(t.exprs); (void)hipFree(t.mats);
+        (void)hipFree(t.comps); (void)hipFree(t.facts); (void)hipFree(t.prog); (void)hipFree(t.consts);
+        if (t.wave) (void)hipFree(t.wave);
+    }
+    c.tables.clear();
 }
 
 }  // namespace qk
@@ -710,16 +724,17 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     qk_circuit& c = *const_cast<qk_circuit*>(cc);
     if (c.n_params > 0 && (!X_dev || ldx < c.n_params))
         return fail(QK_ERR_INVALID, "qk_simulate_dev: X is null or its row stride is smaller than the parameter count");
-    int rc = upload_circuit(c);
+    DevTables dt;
+    int rc = upload_circuit(c, dt);
     if (rc) return rc;
     const int n = c.n_qubits;
     // up to 10 qubits: the wave-resident kernel (qk_wave.hip) -- the state never leaves the registers of one
     // wavefront.  QK_SIM_PATH=lds keeps such circuits on the LDS kernel below (A/B runs, and the fused
     // simulate + RDM mode, which reduces from the LDS image).
     static const bool force_lds = [] { const char* e = std::getenv("QK_SIM_PATH"); return e && std::strcmp(e, "lds") == 0; }();
-    if (c.d_wave && !rdm_dev && !force_lds) {
+    if (dt.wave && !rdm_dev && !force_lds) {
         WaveJob job{};
-        job.prog = c.d_wave;
+        job.prog = dt.wave;
         job.X = X_dev;
         job.ldx = ldx;
         job.N = N;
@@ -747,15 +762,15 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.psi = (double2*)psi_dev;
         a.rdm = rdm_dev;
         a.D = (int64_t)1 << n;
-        a.stages = c.d_stages + ps.stage_off;
-        a.terms = c.d_terms + ps.term_off;
-        a.exprs = c.d_exprs + ps.expr_off;
-        a.mats = c.d_mats + ps.mat_off;
-        a.comps = c.d_comps + ps.comp_off;
-        a.facts = c.d_facts + ps.fact_off;
+        a.stages = dt.stages + ps.stage_off;
+        a.terms = dt.terms + ps.term_off;
+        a.exprs = dt.exprs + ps.expr_off;
+        a.mats = dt.mats + ps.mat_off;
+        a.comps = dt.comps + ps.comp_off;
+        a.facts = dt.facts + ps.fact_off;
         a.n_comp = ps.n_comp;
-        a.prog = c.d_prog;
-        a.consts = c.d_consts;
+        a.prog = dt.prog;
+        a.consts = dt.consts;
         a.n_stage = ps.n_stage;
         a.n_expr = ps.n_expr;
         a.n_mat = ps.n_mat;
