@@ -499,6 +499,21 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         if (pi + 1 < drafts.size())
             ps.zero_out = mask_of(~active & ((n >= 32) ? 0xffffffffu : ((1u << n) - 1u)));
         ps.n_stage = (int)c.stages.size() - ps.stage_off;
+        // The angle programs of a pass run one per lane, and a wave pays for every distinct operation its lanes are
+        // at in a step: programs of one shape (the same operations, other features and constants) side by side
+        // keep the interpreter's switch from diverging.  Every entry carries its destination, so the order is free.
+        {
+            auto shape = [&](const DevExpr& e) {
+                uint64_t hsh = 1469598103934665603ull;
+                for (int k = 0; k < e.len; ++k) hsh = (hsh ^ (uint64_t)(c.prog[e.start + k].op + 1)) * 1099511628211ull;
+                return hsh ^ (uint64_t)e.len;
+            };
+            std::stable_sort(c.exprs.begin() + ps.expr_off, c.exprs.end(),
+                             [&](const DevExpr& x, const DevExpr& y) {
+                                 if (x.len != y.len) return x.len > y.len;     // long programs first: they share the early steps
+                                 return shape(x) < shape(y);
+                             });
+        }
         ps.n_expr = (int)c.exprs.size() - ps.expr_off;
         ps.n_term = (int)c.terms.size() - ps.term_off;
         ps.n_mat = (int)c.mats.size() - ps.mat_off;

@@ -52,4 +52,42 @@ QK_HD void sincos_cw(double x, double* sn, double* cs) {
     *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// The postfix machine of the gate angles (programs validated on the host, qk_circuit_create: at most 8 stack
+// slots), shared by both simulators.  The stack is eight named registers that shift on push and pop -- an array
+// indexed by the stack pointer lives in scratch memory, and every push and pop becomes a round trip to it
+// (the LDS simulator spent 11 us per sample there at 12 qubits: tools/sim_trace.py).
+struct AngleStack {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+    __device__ __forceinline__ void push(double v) { s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v; }
+    __device__ __forceinline__ void drop() { s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; }   // pop the top
+};
+
+// value of one angle program on the feature row xrow.  The lanes of a wave run different programs, so a step costs
+// the sum of the distinct operations its lanes are at (about 3 us per sample for the 46 angles of a 12-qubit ZZ
+// map r = 2: tools/sim_trace.py); fetching instructions and operands ahead of their use bought nothing -- the
+// loop is bound by the instructions of the divergent switch, not by its reads.
+template <class ProgPtr, class ConstPtr>
+__device__ __forceinline__ double run_postfix(ProgPtr prog, int start, int len, ConstPtr consts, const double* xrow) {
+    AngleStack st;
+    for (int k = 0; k < len; ++k) {
+        const qk_instr in = prog[start + k];
+        const double a = st.s0, b = st.s1;    // top, second
+        switch (in.op) {
+            case QK_EX_CONST: st.push(consts[in.arg]); break;
+            case QK_EX_PARAM: st.push(xrow[in.arg]); break;
+            case QK_EX_ADD: st.drop(); st.s0 = b + a; break;
+            case QK_EX_SUB: st.drop(); st.s0 = b - a; break;
+            case QK_EX_MUL: st.drop(); st.s0 = b * a; break;
+            case QK_EX_DIV: st.drop(); st.s0 = b / a; break;
+            case QK_EX_NEG: st.s0 = -a; break;
+            case QK_EX_ASIN: st.s0 = asin(a); break;
+            case QK_EX_ACOS: st.s0 = acos(a); break;
+            case QK_EX_SIN: st.s0 = sin(a); break;
+            case QK_EX_COS: st.s0 = cos(a); break;
+            default: break;
+        }
+    }
+    return st.s0;
+}
+
 }  // namespace qk

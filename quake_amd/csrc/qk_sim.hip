@@ -54,7 +54,16 @@ struct SimArgs {
     int nruns;
     uint32_t run_mask[kMaxRuns];
     int32_t run_shift[kMaxRuns];
+    double* trace;               // phase-timing builds only (QK_SIM_TRACE): 16 doubles per workgroup
 };
+
+// Phase-timing builds (tools/sim_trace.sh compiles this file again with -DQK_SIM_TRACE into a separate library):
+// thread 0 of every workgroup adds up the 100 MHz ticks between the marks below and leaves the sums in a table.
+#ifdef QK_SIM_TRACE
+#define QK_MARK(k) do { if (tid == 0) { const uint64_t t_ = wall_clock64(); tr_acc[k] += (double)(t_ - tr_last); tr_last = t_; } } while (0)
+#else
+#define QK_MARK(k) do { } while (0)
+#endif
 
 // a diagonal term with its per-sample (cos, sin) resolved, 32 bytes in LDS
 struct RTerm {
@@ -71,6 +80,9 @@ __device__ __forceinline__ double2 cfma(double2 a, double2 b, double2 c) {  // a
 
 __device__ __forceinline__ uint32_t deposit(uint32_t w, const SimArgs& a) {
     uint32_t g = 0;
+    // not unrolled: the unrolled form's trip-count tests ("one run?", "odd number?") are hoisted out of the item
+    // loop as booleans the register allocator then keeps in scratch memory (see the note at the item loop's head)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (int r = 0; r < a.nruns; ++r) {
         const uint32_t m = w & a.run_mask[r];
         const int sh = a.run_shift[r];
@@ -210,27 +222,9 @@ __device__ __forceinline__ void run_angle_programs(ExprPtr exprs, ProgPtr prog, 
                                                    int n_expr, RTerm* rt, double2* mat, int tid, int T) {
     for (int e = tid; e < n_expr; e += T) {
         const DevExpr ex = exprs[e];
-        double st[8];
-        int sp = 0;
-        for (int k = 0; k < ex.len; ++k) {
-            const qk_instr in = prog[ex.start + k];
-            switch (in.op) {
-                case QK_EX_CONST: st[sp++] = consts[in.arg]; break;
-                case QK_EX_PARAM: st[sp++] = xrow[in.arg]; break;
-                case QK_EX_ADD: --sp; st[sp - 1] = st[sp - 1] + st[sp]; break;
-                case QK_EX_SUB: --sp; st[sp - 1] = st[sp - 1] - st[sp]; break;
-                case QK_EX_MUL: --sp; st[sp - 1] = st[sp - 1] * st[sp]; break;
-                case QK_EX_DIV: --sp; st[sp - 1] = st[sp - 1] / st[sp]; break;
-                case QK_EX_NEG: st[sp - 1] = -st[sp - 1]; break;
-                case QK_EX_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
-                case QK_EX_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
-                case QK_EX_SIN: st[sp - 1] = sin(st[sp - 1]); break;
-                case QK_EX_COS: st[sp - 1] = cos(st[sp - 1]); break;
-                default: break;
-            }
-        }
+        const double angle = run_postfix(prog, ex.start, ex.len, consts, xrow);
         double sn, cn;
-        sincos_cw(st[0] * ex.scale, &sn, &cn);   // the routine the wave-resident kernel uses: one set of angles per circuit
+        sincos_cw(angle * ex.scale, &sn, &cn);   // the routine the wave-resident kernel uses: one set of angles per circuit
         if (ex.dst >= 0) {
             rt[ex.dst].c = cn;
             rt[ex.dst].s = sn;
@@ -256,6 +250,13 @@ __device__ __forceinline__ void run_angle_programs(ExprPtr exprs, ProgPtr prog, 
 // MAXG = 3: 512 threads, up to 256 VGPRs (radix-8 sweeps); MAXG = 2: 256 threads, up to 168 VGPRs, 3 waves/SIMD
 // RDM = true: the fused simulate + reduced-density-matrix variant (qk_simulate_rdm1_dev); the reduction
 // holds 16 amplitudes per thread, so it gets the 256-VGPR budget (2 waves/SIMD) of its own instantiation.
+// The workgroup's waves talk to each other through LDS only (statevectors in global memory are written by one
+// pass and read by the next, a separate launch), so its barriers wait for LDS traffic alone.  __syncthreads()
+// also waits for every outstanding global access of the wave (s_waitcnt vmcnt(0)): the first barrier of an item
+// then sat out the drain of the previous item's stores -- about 10 us of a 17-37 us item at 12 qubits
+// (tools/sim_trace.py) -- instead of computing under it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int MAXG, bool RDM>
 __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 : 3) sim_pass_kernel(SimArgs a) {
     extern __shared__ double2 lds[];
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     const int64_t item_end = item_begin + per_wg < a.n_items ? item_begin + per_wg : a.n_items;
     if (item_begin < item_end)
         for (int t = tid; t < a.n_params; t += T) xbuf[t] = a.X[(item_begin >> a.nlive) * a.ldx + t];
-    __syncthreads();
+    lds_barrier();
 
     // Chunks whose amplitudes are all still zero after the pass (and a later pass knows) are not
     // items at all.  In steady state the only vector-memory traffic of a first pass is the store of
@@ -327,19 +328,34 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     // next is computed.
     // A diagonal stage right after the hoisted first gates (every Z / ZZ map) takes the product
     // state as two more factors of its tables: the state is written once, phases included.
-    const bool fuse_init = a.first && a.n_init > 0 && a.n_init < a.n_stage && a.stages[a.n_init].kind == ST_DIAG;
+    // (readfirstlane: the value comes from a vector load, and a per-lane boolean that lives across the item loop
+    // ends up in scratch memory)
+    const bool fuse_init = a.first && a.n_init > 0 && a.n_init < a.n_stage &&
+                           __builtin_amdgcn_readfirstlane(a.stages[a.n_init].kind) == ST_DIAG;
     // Several chunks per sample: what those tables owe to local bits only (the product state's factors,
     // the terms without a chunk bit, the cross-term ratios) is computed once per sample; a chunk
     // multiplies in its scalar and the few terms that read a chunk bit.
     const bool hoist = a.hoist != 0;    // = fuse_init, decided by the host with the LDS layout
     int par = 0;
     int64_t angles_of = -1;     // the sample whose (cos, sin) values sit in rt / mat
+#ifdef QK_SIM_TRACE
+    double tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 load + angles + tables, 1 product state, 2 diag tables, 3 diag sweep, 4 u1, 5 cx / ecr, 6 store, 7 items
+    uint64_t tr_last = wall_clock64();
+    const uint64_t tr_begin = tr_last;
+    uint64_t tr_angles = 0, tr_pre = 0;
+#endif
     for (int64_t item = item_begin; item < item_end; ++item) {
         const int64_t next = item + 1;
         const bool fetch = next < item_end && (next >> a.nlive) != (item >> a.nlive);
-        const bool have_next = fetch && tid < a.n_params;
+        // The addresses of the feature-row prefetch are recomputed per item from an opaque copy of the thread index:
+        // hoisted out of the loop they end up spilled, and a reload from scratch memory at the top of an item
+        // waits (memory operations return in order) for every store of the previous item -- the drain this loop
+        // is built to compute under (10 us of a 17-37 us item at 12 qubits: tools/sim_trace.py).
+        int tid_x = tid;
+        asm volatile("" : "+v"(tid_x));
+        const bool have_next = fetch && tid_x < a.n_params;
         double xnext = 0.0;
-        if (have_next) xnext = a.X[(next >> a.nlive) * a.ldx + tid];   // in flight until the end of the item
+        if (have_next) xnext = a.X[(next >> a.nlive) * a.ldx + tid_x];   // in flight until the end of the item
         uint32_t chunk = 0;
         {
             uint32_t ci = (uint32_t)(item & ((1u << a.nlive) - 1u)), m = a.live_chunks;
@@ -368,13 +384,19 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             }
         }
         // ---- per-sample gate angles -> (cos, sin) into their term or matrix ---------------
+#ifdef QK_SIM_TRACE
+        if (tid == 0) tr_pre += wall_clock64() - tr_last;
+#endif
         if (sample != angles_of) {
-            if (a.staged) run_angle_programs(s_expr, s_prog, s_const, xrow, a.n_expr, rt, mat, tid, T);
-            else run_angle_programs(a.exprs, a.prog, a.consts, xrow, a.n_expr, rt, mat, tid, T);
+            if (a.staged) run_angle_programs(s_expr, s_prog, s_const, xrow, a.n_expr, rt, mat, tid_x, T);
+            else run_angle_programs(a.exprs, a.prog, a.consts, xrow, a.n_expr, rt, mat, tid_x, T);
             angles_of = sample;
+#ifdef QK_SIM_TRACE
+            if (tid == 0) tr_angles += wall_clock64() - tr_last;
+#endif
             if (a.n_comp) {     // runs of single-qubit gates on one qubit: one thread multiplies a run's factors
-                __syncthreads();
-                for (int k = tid; k < a.n_comp; k += T) {
+                lds_barrier();
+                for (int k = tid_x; k < a.n_comp; k += T) {
                     const DevComp cc = a.comps[k];
                     const int32_t* f = a.facts + cc.first;
                     double2 m0 = mat[4 * f[0]], m1 = mat[4 * f[0] + 1], m2 = mat[4 * f[0] + 2], m3 = mat[4 * f[0] + 3];
@@ -389,7 +411,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 }
             }
             if (hoist) {
-                __syncthreads();
+                lds_barrier();
                 const DevStage st = a.stages[a.n_init];
                 const RTerm* tl = rt + st.t0;
                 const RTerm* th = tl + st.nLo;
@@ -406,7 +428,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         const int2 g = s_init[q];
                         if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
                     }
-                for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
+                for (uint32_t j = (uint32_t)tid_x; j < n_rat + nlo + nhi; j += T) {
                     double fr = 1.0, fi = 0.0;
                     if (j < n_rat) {
                         const uint32_t c = j & (nlo - 1u);
@@ -442,7 +464,8 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        QK_MARK(0);
 
         // ---- first pass: the product state of the hoisted first gates -----------------------
         // amplitude(w) = prod_q U_q[w_q][0] over the initialised qubits, 0 where a bit of an
@@ -469,7 +492,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                     thi[j - nlo] = f;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         } else if (a.first && !hoist) {
             const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
             double2 gs = make_double2((whi & a.zero_in) ? 0.0 : 1.0, 0.0);
@@ -487,13 +510,14 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 }
                 (is_lo ? tlo[j] : thi[j - nlo]) = f;
             }
-            __syncthreads();
+            lds_barrier();
             if (!fuse_init) {
                 for (uint32_t l = tid; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
-                __syncthreads();
+                lds_barrier();
             }
         }
 
+        QK_MARK(1);
         // ---- stages -----------------------------------------------------------------------
         for (int s = a.first ? a.n_init : 0; s < a.n_stage; ++s) {
             const DevStage st = a.stages[s];
@@ -539,7 +563,8 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         thi[r] = fused ? cmul(thi[r], make_double2(fr, fi)) : make_double2(fr, fi);
                     }
                 }
-                __syncthreads();
+                lds_barrier();
+                QK_MARK(2);
                 if (st.nX == 0) {
                     if (fused && to_hbm) {
                         for (uint32_t l = tid; l < nloc; l += T) store_direct(l, cmul(tlo[l & (nlo - 1u)], thi[l >> h]));
@@ -629,13 +654,14 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                     state[j3] = make_double2(r * (a2.x + a0.y), r * (a2.y - a0.x));
                 }
             }
-            __syncthreads();
+            lds_barrier();
+            QK_MARK(st.kind == ST_DIAG ? 3 : (st.kind == ST_U1 ? 4 : 5));
         }
         // ---- write back (amplitudes that are still known-zero are left to the next pass) ------
-        if (have_next) xbuf[(par ^ 1) * xs + tid] = xnext;
+        if (have_next) xbuf[(par ^ 1) * xs + tid_x] = xnext;
         if (fetch)   // more features than threads: the rest without the register detour
-            for (int t = tid + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
-        __syncthreads();
+            for (int t = tid_x + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
+        lds_barrier();
         if constexpr (RDM) rdm1_from_lds(state, L, s_red, a.rdm + sample * (L * 4), tid, T);
         if (a.direct || a.last_direct) {
             // already stored by the (last) diagonal stage
@@ -653,7 +679,20 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         // before it issued its stores, and the stores themselves need not have landed.
         __builtin_amdgcn_s_barrier();
         if (fetch) par ^= 1;
+        QK_MARK(6);
+#ifdef QK_SIM_TRACE
+        if (tid == 0) tr_acc[7] += 1.0;
+#endif
     }
+#ifdef QK_SIM_TRACE
+    if (tid == 0 && a.trace) {
+        for (int k = 0; k < 8; ++k) a.trace[(int64_t)blockIdx.x * 16 + k] = tr_acc[k];
+        a.trace[(int64_t)blockIdx.x * 16 + 8] = (double)tr_angles;                    // part of slot 0: up to the end of thread 0's angle program
+        a.trace[(int64_t)blockIdx.x * 16 + 9] = (double)(wall_clock64() - tr_begin);  // the workgroup's whole item loop
+        a.trace[(int64_t)blockIdx.x * 16 + 10] = (double)tr_begin;
+        a.trace[(int64_t)blockIdx.x * 16 + 11] = (double)tr_pre;                      // part of slot 0: up to the start of the angle programs
+    }
+#endif
 }
 
 int upload_circuit(qk_circuit& c, DevTables& out) {
@@ -715,6 +754,11 @@ void free_circuit_device(qk_circuit& c) {
 
 }  // namespace qk
 
+#ifdef QK_SIM_TRACE
+static std::atomic<double*> g_sim_trace{nullptr};
+extern "C" void qk_sim_set_trace(double* table_dev) { g_sim_trace = table_dev; }
+#endif
+
 namespace qk {
 // psi and / or rdm: rdm != null asks for the fused mode (one pass, one chunk per sample)
 // psi32 != null: the last pass writes complex64 there; with several passes psi_dev (complex128) is
@@ -766,6 +810,9 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.terms = dt.terms + ps.term_off;
         a.exprs = dt.exprs + ps.expr_off;
         a.mats = dt.mats + ps.mat_off;
+#ifdef QK_SIM_TRACE
+        a.trace = g_sim_trace.load();
+#endif
         a.comps = dt.comps + ps.comp_off;
         a.facts = dt.facts + ps.fact_off;
         a.n_comp = ps.n_comp;

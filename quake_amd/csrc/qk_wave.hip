@@ -410,38 +410,10 @@ __device__ __forceinline__ void diag_run(v2d (&amp)[NREG], const WaveTerm* terms
     for (int r = 0; r < NREG; ++r) amp[r] = cmul(amp[r], F);
 }
 
-// one angle: the postfix program (validated on the host, qk_circuit_create: at most 8 stack slots) on this
-// sample's feature row.  The stack is eight named registers that shift on push and pop -- an array indexed by
-// the stack pointer would live in scratch memory.
-struct AngleStack {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
-    __device__ __forceinline__ void push(double v) { s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v; }
-    __device__ __forceinline__ void drop() { s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; }   // pop the top
-};
-
 __device__ __forceinline__ double2 eval_angle(const WaveExpr ex, const qk_instr* prog, const double* consts,
                                               const double* __restrict__ xrow) {
-    AngleStack st;
-    for (int k = 0; k < ex.len; ++k) {
-        const qk_instr in = prog[ex.start + k];
-        double a = st.s0, b = st.s1;    // top, second
-        switch (in.op) {
-            case QK_EX_CONST: st.push(consts[in.arg]); break;
-            case QK_EX_PARAM: st.push(xrow[in.arg]); break;
-            case QK_EX_ADD: st.drop(); st.s0 = b + a; break;
-            case QK_EX_SUB: st.drop(); st.s0 = b - a; break;
-            case QK_EX_MUL: st.drop(); st.s0 = b * a; break;
-            case QK_EX_DIV: st.drop(); st.s0 = b / a; break;
-            case QK_EX_NEG: st.s0 = -a; break;
-            case QK_EX_ASIN: st.s0 = asin(a); break;
-            case QK_EX_ACOS: st.s0 = acos(a); break;
-            case QK_EX_SIN: st.s0 = sin(a); break;
-            case QK_EX_COS: st.s0 = cos(a); break;
-            default: break;
-        }
-    }
     double sn, cn;
-    sincos_cw(st.s0 * ex.scale, &sn, &cn);
+    sincos_cw(run_postfix(prog, ex.start, ex.len, consts, xrow) * ex.scale, &sn, &cn);
     return make_double2(cn, sn);
 }
 

@@ -152,3 +152,23 @@ def test_dlpack_hand_off_in_and_out():
         circ.simulate(X)                                                    # numpy is a CPU DLPack producer: refused, no silent copy
     with pytest.raises(TypeError):
         qdev.gram([1, 2, 3])
+
+
+def test_rccl_smoke_world_size_one():
+    """The collectives of the N > 1 path, in the forms bench.py and sharded.py use them, over RCCL itself (backend
+    "nccl") with as many ranks as this box allows: one.  A child process (this one has initialised the GPU)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "rccl_smoke.py")],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["backend"] == "nccl" and out["all_gather_in_place"] and out["p2p"] and out["all_reduce_max"]
