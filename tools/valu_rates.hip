@@ -1,86 +1,42 @@
-// Issue rate of single VALU instructions on gfx950, relative to v_fma_f64 (which is full rate: 4 cycles
-// per wave64).  One workgroup of 256 threads per CU slot, 8 independent register chains per thread.
-// Build: hipcc -O3 --offload-arch=gfx950 tools/valu_rates.hip -o gpurun_out/valu_rates
+// Issue cost of FP64 vector instructions on gfx950, one wave per SIMD: tools/valu_rates.hip -> cycles per instruction.
+// hipcc -O3 --offload-arch=gfx950 tools/valu_rates.hip -o tools/valu_rates.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
-
-#define KERNEL(NAME, TYPE, CONSTRAINT, ASM)                                             \
-    __global__ void __launch_bounds__(256) NAME(TYPE* out, int iters) {                 \
-        TYPE r[8];                                                                      \
-        for (int k = 0; k < 8; ++k) r[k] = (TYPE)(1.5 + threadIdx.x * 1e-3 + k);        \
-        for (int it = 0; it < iters; ++it) {                                            \
-            _Pragma("unroll") for (int rep = 0; rep < 4; ++rep)                         \
-            _Pragma("unroll") for (int k = 0; k < 8; ++k) asm volatile(ASM : "+" CONSTRAINT(r[k])); \
-        }                                                                               \
-        TYPE s = 0;                                                                     \
-        for (int k = 0; k < 8; ++k) s += r[k];                                          \
-        out[blockIdx.x * 256 + threadIdx.x] = s;                                        \
+#define REP8(X) X X X X X X X X
+template <int K>
+__global__ void __launch_bounds__(64) k(double* out, int iters) {
+    double a0 = threadIdx.x + 1.5, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    float f0 = (float)a0, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3;
+    for (int i = 0; i < iters; ++i) {
+        if constexpr (K == 0) { REP8(asm volatile("v_fma_f64 %0, %0, %0, %0\n v_fma_f64 %1, %1, %1, %1\n v_fma_f64 %2, %2, %2, %2\n v_fma_f64 %3, %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if constexpr (K == 1) { REP8(asm volatile("v_rsq_f64 %0, %0\n v_rsq_f64 %1, %1\n v_rsq_f64 %2, %2\n v_rsq_f64 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if constexpr (K == 2) { REP8(asm volatile("v_rsq_f32 %0, %0\n v_rsq_f32 %1, %1\n v_rsq_f32 %2, %2\n v_rsq_f32 %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));) }
+        if constexpr (K == 3) { REP8(asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));) }
+        if constexpr (K == 4) { REP8(asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f0), "v"(f1), "v"(f2), "v"(f3));) }
+        if constexpr (K == 5) { REP8(asm volatile("v_add_f64 %0, %0, %0\n v_add_f64 %1, %1, %1\n v_add_f64 %2, %2, %2\n v_add_f64 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if constexpr (K == 6) { REP8(asm volatile("v_mul_f64 %0, %0, %0\n v_mul_f64 %1, %1, %1\n v_mul_f64 %2, %2, %2\n v_mul_f64 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if constexpr (K == 7) { REP8(asm volatile("v_sqrt_f64 %0, %0\n v_sqrt_f64 %1, %1\n v_sqrt_f64 %2, %2\n v_sqrt_f64 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if constexpr (K == 8) { REP8(asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));) }
+        if constexpr (K == 9) { REP8(asm volatile("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
     }
-
-KERNEL(k_fma64, double, "v", "v_fma_f64 %0, %0, %0, %0")
-KERNEL(k_mul64, double, "v", "v_mul_f64 %0, %0, %0")
-KERNEL(k_rsq64, double, "v", "v_rsq_f64 %0, %0")
-KERNEL(k_rcp64, double, "v", "v_rcp_f64 %0, %0")
-KERNEL(k_sqrt64, double, "v", "v_sqrt_f64 %0, %0")
-KERNEL(k_rsq32, float, "v", "v_rsq_f32 %0, %0")
-KERNEL(k_sqrt32, float, "v", "v_sqrt_f32 %0, %0")
-KERNEL(k_fma32, float, "v", "v_fma_f32 %0, %0, %0, %0")
-KERNEL(k_exp32, float, "v", "v_exp_f32 %0, %0")
-
-__global__ void __launch_bounds__(256) k_cvt(double* out, int iters) {
-    double r[8];
-    for (int k = 0; k < 8; ++k) r[k] = 1.5 + threadIdx.x * 1e-3 + k;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int rep = 0; rep < 2; ++rep)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float f;
-                asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f) : "v"(r[k]));
-                asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(r[k]) : "v"(f));
-            }
-    }
-    double s = 0;
-    for (int k = 0; k < 8; ++k) s += r[k];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + f0 + f1 + f2 + f3;
 }
-
-template <typename T, typename F>
-static int run(const char* name, F kernel, double base_ms, double* base_out) {
-    T* out;
-    const int blocks = 256 * 8, iters = 20000;
-    CHK(hipMalloc(&out, blocks * 256 * sizeof(T)));
-    hipEvent_t a, b;
-    CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, 100);
-    CHK(hipEventRecord(a));
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, iters);
-    CHK(hipEventRecord(b));
-    CHK(hipEventSynchronize(b));
-    float ms;
-    CHK(hipEventElapsedTime(&ms, a, b));
-    // wave instructions per SIMD: blocks * 4 waves * iters * 32 / 1024 SIMDs
-    const double per_simd = (double)blocks * 4 * iters * 32 / 1024;
-    if (base_out) *base_out = ms;
-    printf("%-10s %8.2f ms  %6.2f ns per wave-instruction per SIMD", name, ms, ms * 1e6 / per_simd);
-    if (base_ms > 0) printf("  = %.2f x v_fma_f64 (x4 cycles = %.1f cycles)", ms / base_ms, 4.0 * ms / base_ms);
-    printf("\n");
-    CHK(hipFree(out));
-    return 0;
+template <int K> void run(const char* name, double* out, int waves_per_simd) {
+    const int iters = 4096, blocks = 256 * 4 * waves_per_simd;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<K><<<blocks, 64>>>(out, 64);
+    hipDeviceSynchronize();
+    hipEventRecord(e0); k<K><<<blocks, 64>>>(out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double per = ms * 1e-3 * 2.4e9 / ((double)iters * 32 * waves_per_simd);
+    printf("%-14s waves/SIMD %d: %.2f cycles per instruction and wave (at 2.4 GHz)\n", name, waves_per_simd, per);
 }
-
 int main() {
-    double base = 0;
-    if (run<double>("fma_f64", k_fma64, 0, &base)) return 1;
-    run<double>("mul_f64", k_mul64, base, nullptr);
-    run<double>("rsq_f64", k_rsq64, base, nullptr);
-    run<double>("rcp_f64", k_rcp64, base, nullptr);
-    run<double>("sqrt_f64", k_sqrt64, base, nullptr);
-    run<float>("fma_f32", k_fma32, base, nullptr);
-    run<float>("rsq_f32", k_rsq32, base, nullptr);
-    run<float>("sqrt_f32", k_sqrt32, base, nullptr);
-    run<float>("exp_f32", k_exp32, base, nullptr);
-    run<double>("cvt pair", k_cvt, base, nullptr);   // 16 cvt_f32_f64 + 16 cvt_f64_f32 per iteration: same count of 32
+    double* out; hipMalloc(&out, 256 * 4 * 4 * 64 * 8);
+    for (int w : {1, 2}) {
+        run<0>("v_fma_f64", out, w); run<5>("v_add_f64", out, w); run<6>("v_mul_f64", out, w); run<1>("v_rsq_f64", out, w);
+        run<7>("v_sqrt_f64", out, w); run<9>("v_rcp_f64", out, w); run<2>("v_rsq_f32", out, w); run<3>("v_cvt_f32_f64", out, w);
+        run<4>("v_cvt_f64_f32", out, w); run<8>("v_fma_f32", out, w);
+    }
     return 0;
 }
