@@ -95,9 +95,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         bool any = false;
         auto flush_q = [&](int q) {
             std::vector<Item>& ch = chain[q];
-            int first_nd = -1, last_nd = -1, nd = 0;
-            for (int k = 0; k < (int)ch.size(); ++k)
-                if (!ch[k].diag) { if (first_nd < 0) first_nd = k; last_nd = k; ++nd; }
+            int nd = 0;
+            for (const Item& g : ch) nd += g.diag ? 0 : 1;
             if (nd < 2) {
                 out.insert(out.end(), ch.begin(), ch.end());
             } else {
@@ -110,7 +109,6 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 out.push_back(Item{false, ST_U1, QK_UC, q, -1, (int32_t)comps.size()});
                 comps.push_back(std::move(fs));
             }
-            (void)first_nd; (void)last_nd;
             ch.clear();
         };
         for (const Item& it : items) {
