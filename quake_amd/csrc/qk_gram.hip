@@ -1077,6 +1077,181 @@ gram32_dma_kernel(GramArgs args) {
     gram32_epilogue<TM, TN>(hre, him, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
 }
 
+// ---- FP32 ring kernel: gram_ring_kernel's loop and LDS ring (stages of 8 units = 16 amplitudes) with the FP32
+// arithmetic of gram32_dma_kernel above (one 16-byte unit feeds two MFMA k-steps, 3-multiplication product, the
+// running accumulators folded into (Re, Im) every 1024 amplitudes).
+template <int NST>
+__global__ void __launch_bounds__(256, NST == 3 ? 3 : 2)
+gram32_ring_kernel(GramArgs args) {
+    constexpr int TM = 2, TN = 2, WAVES_N = 2, WAVES = 4, BM = 64, BN = 64;
+    constexpr int STAGE = (BM + BN) * 128;          // bytes
+    constexpr int NA = BM / 8 / WAVES, NB = BN / 8 / WAVES, NE = NA + NB;
+    constexpr int INFLIGHT = NE * (NST - 2);
+    constexpr int FLUSH = 64;                       // stages per first-level accumulation run (1024 amplitudes)
+    static_assert(NST == 3 || NST == 5, "ring of 3 or 5 stages");
+    extern __shared__ v4f smem32[];
+    GramJobDev J;
+    int ti, tj;
+    if (!gram_locate(args, J, ti, tj)) return;
+    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const uint32_t U = (uint32_t)(args.D >> 1);     // 16-byte units per row; the host checks D <= 2^22
+    const int64_t row0 = (int64_t)ti * BM, col0 = (int64_t)tj * BN;
+    const int64_t ma = J.ma, nb = J.nb;
+
+    uint32_t vo[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int j = e < NA ? e : e - NA;
+        const int row = 8 * (wave + WAVES * j) + (lane >> 3);
+        const int64_t first = e < NA ? row0 : col0, last = (e < NA ? ma : nb) - 1;
+        const uint32_t rr = (uint32_t)(min(first + row, last) - first);
+        vo[e] = (rr * U + (uint32_t)((lane & 7) ^ ((row >> 1) & 7))) * 16u;
+    }
+    const char* Ab = (const char*)J.A + row0 * (int64_t)U * 16;
+    const char* Bb = (const char*)J.B + col0 * (int64_t)U * 16;
+    char* const lds = (char*)smem32;
+    auto dma = [&](int buf, uint32_t koff, int e) __attribute__((always_inline)) {
+        const int j = e < NA ? e : e - NA;
+        const char* src = (e < NA ? Ab : Bb) + koff;
+        char* dst = lds + buf * STAGE + (e < NA ? 0 : BM * 128) + (wave + WAVES * j) * 1024;
+        asm volatile("" : "+v"(vo[e]));
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + (uint64_t)vo[e]), (lptr_t)dst, 16, 0, 0);
+    };
+    auto wait_next_stage = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+    };
+
+    v4f acc[3][TM][TN], hre[TM][TN], him[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            acc[0][m][n] = acc[1][m][n] = acc[2][m][n] = (v4f){0, 0, 0, 0};
+            hre[m][n] = him[m][n] = (v4f){0, 0, 0, 0};
+        }
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                hre[m][n] += acc[0][m][n] + acc[1][m][n];
+                him[m][n] += acc[2][m][n] + (acc[0][m][n] - acc[1][m][n]);
+                acc[0][m][n] = acc[1][m][n] = acc[2][m][n] = (v4f){0, 0, 0, 0};
+            }
+    };
+
+    const int stages = (int)(U >> 3);
+    const int lastst = stages - 1;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dma(s, (uint32_t)min(s, lastst) * 128u, e);
+    wait_next_stage();
+
+    const int frag_k = lane >> 4, frag_r = lane & 15;
+    typedef const __attribute__((address_space(3))) v4f* lfrag_t;
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem32;
+    uint32_t fa[2], fb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int x = (4 * kk + frag_k) ^ (frag_r >> 1);
+        fa[kk] = lds0 + (uint32_t)((wm * (TM * 16) + frag_r) * 128 + x * 16);
+        fb[kk] = lds0 + (uint32_t)(BM * 128 + (wn * (TN * 16) + frag_r) * 128 + x * 16);
+        asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));
+    }
+    v4f a[TM], b[TN];
+    auto read_frags = [&](int buf, int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) a[m] = *(lfrag_t)(size_t)(fa[kk] + (uint32_t)(buf * STAGE + m * 2048));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) b[n] = *(lfrag_t)(size_t)(fb[kk] + (uint32_t)(buf * STAGE + n * 2048));
+    };
+    read_frags(0, 0);
+
+    auto stage = [&](auto s_c, int hh) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value;
+        const uint32_t koff = (uint32_t)min(hh + NST - 1, lastst) * 128u;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            float sa[2][TM], db[2][TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m) { sa[0][m] = a[m].x + a[m].y; sa[1][m] = a[m].z + a[m].w; }
+#pragma unroll
+            for (int n = 0; n < TN; ++n) { db[0][n] = b[n].y - b[n].x; db[1][n] = b[n].w - b[n].z; }
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if ((e & 1) == kk) dma((S + NST - 1) % NST, koff, e);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[2][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][m], db[0][n], acc[2][m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b[n].z, acc[0][m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b[n].w, acc[1][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk == 0) {
+                read_frags(S, 1);
+            } else {
+                wait_next_stage();
+                read_frags((S + 1) % NST, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[2][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][m], db[1][n], acc[2][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (((hh + 1) & (FLUSH - 1)) == 0) flush();
+    };
+    using std::integral_constant;
+    int h = 0;
+    for (; h + NST <= stages; h += NST) {
+        stage(integral_constant<int, 0>{}, h);
+        stage(integral_constant<int, 1>{}, h + 1);
+        stage(integral_constant<int, 2>{}, h + 2);
+        if constexpr (NST == 5) {
+            stage(integral_constant<int, 3>{}, h + 3);
+            stage(integral_constant<int, 4>{}, h + 4);
+        }
+    }
+    if (h < stages) stage(integral_constant<int, 0>{}, h);
+    if (h + 1 < stages) stage(integral_constant<int, 1>{}, h + 1);
+    if constexpr (NST == 5) {
+        if (h + 2 < stages) stage(integral_constant<int, 2>{}, h + 2);
+        if (h + 3 < stages) stage(integral_constant<int, 3>{}, h + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flush();
+    gram32_epilogue<TM, TN>(hre, him, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
+}
+
 // D < 32 (under 5 qubits): one thread per entry, FP32 products accumulated in order.
 __global__ void __launch_bounds__(256) gram32_small_kernel(GramArgs args) {
     const GramJobDev& J = args.job[0];
@@ -1321,6 +1496,23 @@ static int launch_gram32(const qk_gram_job* jobs, int n_jobs, int64_t D, hipStre
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
+template <int NST>
+static int launch_gram32_ring(const qk_gram_job* jobs, int n_jobs, int64_t D, hipStream_t stream) {
+    GramArgs args;
+    int64_t blocks = 0;
+    const int rc = build_gram_args(jobs, n_jobs, D, 64, 64, 3, 3, "qk_gram32_jobs_dev", args, blocks);
+    if (rc) return rc;
+    if (args.n_jobs == 0) return QK_OK;
+    constexpr int lds = NST * 128 * 128;
+    static DeviceOnce attr_set;
+    if (attr_set.pending()) {
+        QK_HIP(hipFuncSetAttribute((const void*)gram32_ring_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set.done();
+    }
+    hipLaunchKernelGGL((gram32_ring_kernel<NST>), dim3((unsigned)blocks), dim3(256), lds, stream, args);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
 static std::atomic<int> g_tile32{0};   // 0 = choose per call, 64 / 128 = forced (QK_GRAM32_TILE, A/B runs)
 }  // namespace qk
 
@@ -1348,9 +1540,12 @@ extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D
     if (!env_read.exchange(true)) {
         if (const char* e = std::getenv("QK_GRAM32_TILE")) g_tile32 = std::atoi(e);
     }
-    const bool big = g_tile32.load() == 128;   // 64 x 64 tiles measured faster at every size (168 vs 166 TFLOP/s at N = 65536, n = 16)
-    return big ? launch_gram32<2, 4, 4, 2>(jobs, n_jobs, D, (hipStream_t)stream)
-               : launch_gram32<2, 2, 2, 2>(jobs, n_jobs, D, (hipStream_t)stream);
+    // QK_GRAM32_TILE=64 / 128: the round-1 kernels (A/B runs); default: the ring kernels, as in FP64
+    const int forced = g_tile32.load();
+    if (forced == 128) return launch_gram32<2, 4, 4, 2>(jobs, n_jobs, D, (hipStream_t)stream);
+    if (forced == 64 || D > ((int64_t)1 << 22)) return launch_gram32<2, 2, 2, 2>(jobs, n_jobs, D, (hipStream_t)stream);
+    return D <= 1024 ? launch_gram32_ring<3>(jobs, n_jobs, D, (hipStream_t)stream)
+                     : launch_gram32_ring<5>(jobs, n_jobs, D, (hipStream_t)stream);
 }
 
 extern "C" int qk_gram_dev(const void* psi_x, int64_t N, const void* psi_y, int64_t M, int64_t D,
