@@ -60,6 +60,8 @@ struct GramArgs {
     int64_t D;  // amplitudes per row
     int64_t ld; // row stride of A and B in amplitudes (>= D)
     double* trace;  // timeline builds only (QK_GRAM_ABLATE & 128): 8 doubles per workgroup
+    unsigned int* sync;   // ring kernel, long rows: one arrival counter per cohort of 32 workgroups (null: no pacing)
+    int sync_shift;       // log2 of the trips of the stage loop (NST stages each) between two meetings of a cohort
 };
 
 // Which block tile does this workgroup compute?  Returns false for padding workgroups.
@@ -388,6 +390,9 @@ struct GramDmaCfg {
     static constexpr size_t LDS_BYTES = (size_t)2 * BUF * 16;
     static_assert(BM % (4 * WAVES) == 0 && BN % (4 * WAVES) == 0, "rows must split evenly over the waves");
 };
+
+constexpr int kSyncCounters = 1 << 16;
+static __device__ unsigned int g_sync_counters[kSyncCounters];   // pacing counters of the ring kernel (see there)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -796,6 +801,34 @@ gram_ring_kernel(GramArgs args) {
 
     const int stages = (int)(D >> 3);
     const int lastst = stages - 1;
+    // Pacing (long rows only).  The 32 workgroups that start together on an XCD -- half a group: the two workgroups
+    // of a CU run half a tile apart -- share their A and B row blocks in that XCD's L2 only while they are at the
+    // same place in their rows: 4 MiB hold 13-20 us of the k-loop, and left alone their starts spread over 40 us
+    // and drift (on some boxes of the pool down to a 24 % hit rate; the fabric traffic costs 4-5 % of clock on a
+    // power-bound chip).  At its start and every 2^sync_shift trips of the stage loop thread 0 reports to the
+    // cohort's counter and waits -- bounded: a missing member costs time, never progress -- until all of them have.
+    unsigned int* sync_cnt = nullptr;
+    unsigned int sync_members = 0, sync_epoch = 0;
+    if (args.sync) {
+        const int64_t lb = (int64_t)blockIdx.x - J.block_begin;
+        const int64_t seq = lb >> 3;
+        const int64_t t_first = ((((seq >> 6) * 8 + (lb & 7)) << 6) + (seq & 63)) - (seq & 31);    // as in gram_locate (8 x 8 groups)
+        const int64_t left = J.live - t_first;
+        sync_members = (unsigned int)(left < 32 ? left : 32);
+        sync_cnt = args.sync + (((int64_t)blockIdx.x >> 8) * 8 + (blockIdx.x & 7));    // 32 consecutive positions of one XCD label
+    }
+    auto meet = [&](int limit) __attribute__((always_inline)) {
+        if (threadIdx.x == 0) {
+            ++sync_epoch;
+            const unsigned int target = sync_members * sync_epoch;
+            atomicAdd(sync_cnt, 1u);
+            for (int spin = 0; spin < limit; ++spin) {       // x s_sleep(8) = 512 cycles
+                if (__hip_atomic_load(sync_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    };
+    if (sync_cnt) meet(400);
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
 #pragma unroll
@@ -868,7 +901,9 @@ gram_ring_kernel(GramArgs args) {
     };
     using std::integral_constant;
     int h = 0;
-    for (; h + NST <= stages; h += NST) {
+    const int meet_mask = (1 << args.sync_shift) - 1;
+    for (int trip = 1; h + NST <= stages; h += NST, ++trip) {
+        if (sync_cnt && (trip & meet_mask) == 0) meet(40);      // scalar test; the other waves meet thread 0 at the next barrier
         stage(integral_constant<int, 0>{}, h);
         stage(integral_constant<int, 1>{}, h + 1);
         stage(integral_constant<int, 2>{}, h + 2);
@@ -1472,6 +1507,25 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
         g_attr_set[vi].done();
     }
     if (QK_GRAM_ABLATE & 128) args.trace = g_trace.load();
+    // Pacing counters of the ring kernel (see gram_ring_kernel): one per cohort of 32 workgroups, cleared in stream
+    // order before the launch.  The table is one static array per device: two launches that overlap on one device
+    // (different streams) clear each other's counters, which costs the earlier one bounded waits (8.5 us per meeting,
+    // a meeting every 0.4 ms) and nothing else -- the counters pace, they do not guard data.
+    // QK_GRAM_PACE=0 turns pacing off, any other value is log2 of the stage-loop trips between meetings (A/B runs).
+    static const int pace_env = std::getenv("QK_GRAM_PACE") ? std::atoi(std::getenv("QK_GRAM_PACE")) : 7;
+    args.sync_shift = pace_env > 0 ? pace_env : 7;
+    if (pace_env > 0 && vi == kRing5Variant && D >= 4096 && blocks / 32 + 8 <= kSyncCounters) {
+        static std::atomic<unsigned int*> table[64];
+        int dev = 0;
+        QK_HIP(hipGetDevice(&dev));
+        unsigned int* cnt = (dev >= 0 && dev < 64) ? table[dev].load() : nullptr;
+        if (!cnt) {
+            QK_HIP(hipGetSymbolAddress((void**)&cnt, HIP_SYMBOL(g_sync_counters)));
+            if (dev >= 0 && dev < 64) table[dev] = cnt;
+        }
+        QK_HIP(hipMemsetAsync(cnt, 0, (size_t)(blocks / 32 + 8) * sizeof(unsigned int), (hipStream_t)stream));
+        args.sync = cnt;
+    }
     V.launch(args, (unsigned)blocks, (hipStream_t)stream);
     QK_HIP(hipGetLastError());
     return QK_OK;
