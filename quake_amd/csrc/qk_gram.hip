@@ -75,54 +75,106 @@ struct GramArgs {
 // keep sharing their A and B row blocks in L2.  (The first version enumerated rectangular macro-tiles and
 // let the workgroups of dead tiles return at once; every one of them shifted a CU by a tile time for the
 // rest of the launch: -2.3 % at N = 65536, n = 16.)
-__device__ __forceinline__ bool gram_locate(const GramArgs& args, GramJobDev& J, int& ti, int& tj) {
-    const int64_t bid = blockIdx.x;
-    // constant indices only: a dynamic index into the kernel-argument struct would copy it to scratch
-    J = args.job[0];
-#pragma unroll
-    for (int k = 1; k < QK_GRAM_MAX_JOBS; ++k)
-        if (k < args.n_jobs && bid >= args.job[k].block_begin) J = args.job[k];
-    const int64_t lb = bid - J.block_begin;
-    const int xcd = (int)(lb & 7);
-    const int64_t seq = lb >> 3;                       // position in this XCD's stream
-    const int lr = args.lr, lc = args.lc;
-    const int64_t group = (seq >> (lr + lc)) * 8 + xcd;
-    int64_t t = (group << (lr + lc)) + (seq & ((1 << (lr + lc)) - 1));   // index in the job's list of live tiles
-    if (t >= J.live) return false;
-    const int br = 1 << lr, TMt = J.tiles_m, TNt = J.tiles_n;
+//
+// Everything here is wave-uniform and written for the scalar unit: 32-bit unsigned arithmetic (the host refuses
+// launches of 2^31 positions or more), no 64-bit compares and no divisions -- the scalar unit has neither, and
+// what the compiler moves to the vector ALU instead waits there behind the MFMAs of the CU's older waves: the
+// first version of this function (int64, t / per_band, u / rb, a 16-way select over the job records) took 26 us
+// of an 88 us tile slot at 8 qubits (timeline build, tools/gram_timeline.py).
+__device__ __forceinline__ uint32_t gram_div_small(uint32_t x, uint32_t d) {   // d = 1 .. 7: constant divisors
+    switch (d) {
+        case 1: return x;
+        case 2: return x >> 1;
+        case 3: return x / 3u;
+        case 4: return x >> 2;
+        case 5: return x / 5u;
+        case 6: return x / 6u;
+        default: return x / 7u;
+    }
+}
+
+__device__ __forceinline__ bool gram_tile_of(const GramJobDev& J, const uint32_t lb, const int lr, const int lc, int& ti, int& tj) {
+    const uint32_t xcd = lb & 7u;
+    const uint32_t seq = lb >> 3;                      // position in this XCD's stream
+    const int g = lr + lc;
+    const uint32_t live = (uint32_t)J.live;
+    const uint32_t full = live >> (g + 3);             // rounds of 8 whole groups
+    uint32_t t;                                        // index in the job's list of live tiles
+    if ((seq >> g) < full) {
+        t = ((((seq >> g) << 3) + xcd) << g) + (seq & ((1u << g) - 1u));
+    } else {
+        // The last, partial round is dealt out evenly, an eighth to each XCD (dealt by whole groups, 2080 tiles
+        // = 32.5 groups of 64 at N = 4096 left one XCD with 288 tiles and seven with 256: the launch took 9 tile
+        // times per CU instead of 8.1).
+        const uint32_t rest = live - (full << (g + 3));
+        const uint32_t chunk = (rest + 7u) >> 3;
+        const uint32_t within = seq - (full << g);
+        if (within >= chunk) return false;
+        t = (full << (g + 3)) + xcd * chunk + within;
+        if (t >= live) return false;
+    }
+    const uint32_t br = 1u << lr, TMt = (uint32_t)J.tiles_m, TNt = (uint32_t)J.tiles_n;
+    uint32_t lo = 0, hi = ((TMt + br - 1u) >> lr) - 1u;    // the band: binary search, every band before `hi` is full
     if (!(J.flags & QK_GRAM_SYMMETRIC)) {
-        const int64_t per_band = (int64_t)br * TNt;
-        const int band = (int)(t / per_band);
-        const int idx = (int)(t - band * per_band);
-        const int rb = min(br, TMt - band * br);
-        tj = idx / rb;
-        ti = band * br + (idx - tj * rb);
+        const uint32_t per_band = TNt << lr;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (mid * per_band <= t) lo = mid; else hi = mid - 1u;
+        }
+        const uint32_t idx = t - lo * per_band;
+        const uint32_t rb = min(br, TMt - (lo << lr));
+        const uint32_t c = rb == br ? idx >> lr : gram_div_small(idx, rb);
+        tj = (int)c;
+        ti = (int)((lo << lr) + (idx - c * rb));
         return true;
     }
-    // symmetric (square tiles): band m holds, for the columns c >= m * br, the rows m * br .. min(c, m * br + rb - 1)
-    int m = 0, rb = 0;
-    for (;; ++m) {
-        const int first = m * br;
-        if (first >= TMt) return false;
-        rb = min(br, TMt - first);
-        const int64_t cnt = (int64_t)rb * (TNt - first) - rb * (rb - 1) / 2;
-        if (t < cnt) break;
-        t -= cnt;
+    // symmetric (square tiles): band m holds, for the columns c >= m * br, the rows m * br .. min(c, m * br + rb - 1):
+    // rb (TNt - m br) - rb (rb - 1) / 2 tiles; m full bands hold m (br TNt - br (br - 1) / 2) - br^2 m (m - 1) / 2
+    const uint32_t per_full = (TNt << lr) - ((br * (br - 1u)) >> 1);
+    auto before = [&](uint32_t m) { return m * per_full - (((m * (m - 1u)) >> 1) << (2 * lr)); };
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (before(mid) <= t) lo = mid; else hi = mid - 1u;
     }
-    const int ragged = rb * (rb - 1) / 2;              // tiles of the first rb - 1 columns (1, 2, ... rows)
-    int k, r;
+    t -= before(lo);
+    const uint32_t first = lo << lr;
+    const uint32_t rb = min(br, TMt - first);
+    const uint32_t ragged = (rb * (rb - 1u)) >> 1;    // tiles of the first rb - 1 columns (1, 2, ... rows)
+    uint32_t k, r;
     if (t < ragged) {
         k = 0;
-        while ((k + 1) * (k + 2) / 2 <= (int)t) ++k;
-        r = (int)t - k * (k + 1) / 2;
+        while (((k + 1u) * (k + 2u)) >> 1 <= t) ++k;
+        r = t - ((k * (k + 1u)) >> 1);
     } else {
-        const int64_t u = t - ragged;
-        k = rb - 1 + (int)(u / rb);
-        r = (int)(u % rb);
+        const uint32_t u = t - ragged;
+        const uint32_t q = rb == br ? u >> lr : gram_div_small(u, rb);
+        k = rb - 1u + q;
+        r = u - q * rb;
     }
-    ti = m * br + r;
-    tj = m * br + k;
+    ti = (int)(first + r);
+    tj = (int)(first + k);
     return true;
+}
+
+// The job record is read through a pointer to the kernel-argument segment: through the by-value struct the
+// compiler loads all 16 records at the top of the kernel (27 scalar loads; 700 spilled SGPRs where the persistent
+// kernel locates its next tile with a full register file); through the pointer it loads the one it needs.
+typedef const __attribute__((address_space(4))) GramArgs* gram_kargs_t;
+__device__ __forceinline__ bool gram_locate(gram_kargs_t ap, const uint32_t bid, GramJobDev& J, int& ti, int& tj) {
+    const int nj = ap->n_jobs;
+    int k = 0;
+    for (int q = 1; q < nj; ++q)
+        if (bid >= (uint32_t)ap->job[q].block_begin) k = q;
+    const __attribute__((address_space(4))) GramJobDev* s = &ap->job[k];
+    J.A = s->A; J.B = s->B; J.K = s->K; J.KT = s->KT;
+    J.ma = s->ma; J.nb = s->nb; J.ldk = s->ldk; J.ldkt = s->ldkt;
+    J.flags = s->flags; J.tiles_m = s->tiles_m; J.tiles_n = s->tiles_n;
+    J.block_begin = s->block_begin; J.live = s->live;
+    return gram_tile_of(J, bid - (uint32_t)J.block_begin, ap->lr, ap->lc, ti, tj);
+}
+// for a kernel whose only argument is GramArgs (offset 0 of the segment)
+__device__ __forceinline__ bool gram_locate(const GramArgs&, const int64_t bid, GramJobDev& J, int& ti, int& tj) {
+    return gram_locate((gram_kargs_t)__builtin_amdgcn_kernarg_segment_ptr(), (uint32_t)bid, J, ti, tj);
 }
 
 // Measurement builds only (tools/gram_ablate.sh compiles this file again with -DQK_GRAM_ABLATE=mask into a
@@ -141,6 +193,52 @@ __device__ __forceinline__ void gram_epilogue(v4d (&acc)[NACC][TM][TN], const Gr
     double* __restrict__ Kp = J.K;
     double* __restrict__ KTp = J.KT;
     const int64_t ldk = J.ldk, ldkt = J.ldkt, ma = J.ma, nb = J.nb;
+    if constexpr (K3M && (QK_GRAM_ABLATE & (32 | 64)) == 0) {
+        // A wave whose 16 TM x 16 TN entries all lie inside the block and (symmetric job) strictly above the
+        // diagonal -- all but the edge and diagonal tiles -- needs no test per entry, and its addresses are a
+        // wave-uniform base (scalar registers and scalar arithmetic) plus one 32-bit lane offset per store
+        // pattern.  That leaves five FP64 operations per entry for the vector ALU, which the waves of the other
+        // workgroups on this CU need for their MFMAs (the general path below: 330 vector instructions per wave,
+        // 10 % of a tile's time at 8 qubits).
+        constexpr int64_t kLd32 = (int64_t)1 << 24;   // 15 rows x ld x 8 B stay below 2^31
+        const bool inside = wrow0 + TM * 16 <= ma && wcol0 + TN * 16 <= nb && (!sym || wrow0 + TM * 16 <= wcol0) &&
+                            ldk <= kLd32 && (!KTp || ldkt <= kLd32);
+        if (__builtin_amdgcn_readfirstlane(inside)) {
+            const uint32_t lr4 = (uint32_t)(lane >> 4), lc16 = (uint32_t)(lane & 15);
+            uint32_t off_d = (lr4 * (uint32_t)ldk + lc16) * 8u;        // K[i][j]
+            uint32_t off_m = (lc16 * (uint32_t)ldk + lr4) * 8u;        // K[j][i]
+            uint32_t off_t = (lc16 * (uint32_t)ldkt + lr4) * 8u;       // KT[j][i]
+            char* const bd = (char*)Kp + (wrow0 * ldk + wcol0) * 8;
+            char* const bm = (char*)Kp + (wcol0 * ldk + wrow0) * 8;
+            char* const bt = (char*)KTp + (wcol0 * ldkt + wrow0) * 8;
+            auto put = [&](char* base, uint32_t& off, double v) __attribute__((always_inline)) {
+                asm volatile("" : "+v"(off));   // keeps zext(off) at the store: selects the SGPR-base form
+                *(double*)(base + (uint64_t)off) = v;
+            };
+            auto all = [&](auto mirror_c, auto kt_c) __attribute__((always_inline)) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double re = acc[0][m][n][r] + acc[1][m][n][r];
+                            const double im = acc[2][m][n][r] + (acc[0][m][n][r] - acc[1][m][n][r]);
+                            const double v = fma(re, re, im * im);
+                            put(bd + ((m * 16 + 4 * r) * ldk + n * 16) * 8, off_d, v);
+                            if constexpr (decltype(mirror_c)::value) put(bm + (n * 16 * ldk + m * 16 + 4 * r) * 8, off_m, v);
+                            if constexpr (decltype(kt_c)::value) put(bt + (n * 16 * ldkt + m * 16 + 4 * r) * 8, off_t, v);
+                        }
+            };
+            using std::true_type;
+            using std::false_type;
+            if (sym && KTp) all(true_type{}, true_type{});
+            else if (sym) all(true_type{}, false_type{});
+            else if (KTp) all(false_type{}, true_type{});
+            else all(false_type{}, false_type{});
+            return;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -194,7 +292,7 @@ gram_kernel(GramArgs args) {
     extern __shared__ v2d smem[];  // [2 buffers][A: BK x LDA | B: BK x LDB]
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, J, ti, tj)) return;
+    if (!gram_locate(args, (int64_t)blockIdx.x, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
 
     const int tid = threadIdx.x;
@@ -406,7 +504,7 @@ gram_dma_kernel(GramArgs args) {
     extern __shared__ v2d smem[];  // [2 buffers][A: BM x 16 | B: BN x 16]
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, J, ti, tj)) return;
+    if (!gram_locate(args, (int64_t)blockIdx.x, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
 
     const int tid = threadIdx.x;
@@ -591,7 +689,7 @@ gram_lean_kernel(GramArgs args) {
     extern __shared__ v2d smem[];  // [2 buffers][A: BM x 16 | B: BN x 16]
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, J, ti, tj)) return;
+    if (!gram_locate(args, (int64_t)blockIdx.x, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
 
     [[maybe_unused]] const uint64_t t_start = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
@@ -754,10 +852,18 @@ gram_ring_kernel(GramArgs args) {
     constexpr int INFLIGHT = NE * (NST - 2);        // DMA instructions of a wave that may stay in flight at a barrier
     static_assert(NST == 3 || NST == 5, "ring of 3 or 5 stages");
     extern __shared__ v2d smem[];  // [NST stages][A | B]
+    // Outside the stage loop a wave runs at raised priority: next to waves that keep the matrix pipe full, a wave
+    // at equal priority is granted about one instruction per MFMA (27 ns) whatever its type -- the timeline build
+    // shows 10-26 us for the few hundred scalar instructions that find the tile, and as much for the epilogue,
+    // during which the workgroup's LDS ring sits idle.
+    __builtin_amdgcn_s_setprio(3);
+    [[maybe_unused]] const uint64_t t_start = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
+    [[maybe_unused]] uint64_t t_first = 0;
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, J, ti, tj)) return;
+    if (!gram_locate(args, (int64_t)blockIdx.x, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
+    [[maybe_unused]] const uint64_t t_located = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -765,15 +871,14 @@ gram_ring_kernel(GramArgs args) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const uint32_t D = (uint32_t)args.D, LD = (uint32_t)args.ld;   // the host checks ld <= 2^22: 63 rows x ld x 16 B fit 32 bits
     const int64_t row0 = (int64_t)ti * BM, col0 = (int64_t)tj * BN;
-    const int64_t ma = J.ma, nb = J.nb;
 
     uint32_t vo[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int j = e < NA ? e : e - NA;
         const int row = 8 * (wave + WAVES * j) + (lane >> 3);
-        const int64_t first = e < NA ? row0 : col0, last = (e < NA ? ma : nb) - 1;
-        const uint32_t rr = (uint32_t)(min(first + row, last) - first);
+        const uint32_t room = (uint32_t)((e < NA ? J.ma - row0 : J.nb - col0) - 1);   // rows of the block past this tile's first (the host checks ma, nb < 2^31); rows beyond the edge re-read the last one
+        const uint32_t rr = min((uint32_t)row, room);
         vo[e] = (rr * LD + (uint32_t)((lane & 7) ^ ((row >> 1) & 7))) * 16u;
     }
     const char* Ab = (const char*)J.A + row0 * (int64_t)LD * 16;   // wave-uniform: scalar registers
@@ -792,13 +897,6 @@ gram_ring_kernel(GramArgs args) {
     };
 
     v4d acc[3][TM][TN];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int n = 0; n < TN; ++n) acc[c][m][n] = (v4d){0, 0, 0, 0};
-
     const int stages = (int)(D >> 3);
     const int lastst = stages - 1;
     // Pacing (long rows only).  The 32 workgroups that start together on an XCD -- half a group: the two workgroups
@@ -809,13 +907,18 @@ gram_ring_kernel(GramArgs args) {
     // cohort's counter and waits -- bounded: a missing member costs time, never progress -- until all of them have.
     unsigned int* sync_cnt = nullptr;
     unsigned int sync_members = 0, sync_epoch = 0;
-    if (args.sync) {
-        const int64_t lb = (int64_t)blockIdx.x - J.block_begin;
-        const int64_t seq = lb >> 3;
-        const int64_t t_first = ((((seq >> 6) * 8 + (lb & 7)) << 6) + (seq & 63)) - (seq & 31);    // as in gram_locate (8 x 8 groups)
-        const int64_t left = J.live - t_first;
-        sync_members = (unsigned int)(left < 32 ? left : 32);
-        sync_cnt = args.sync + (((int64_t)blockIdx.x >> 8) * 8 + (blockIdx.x & 7));    // 32 consecutive positions of one XCD label
+    if (NST == 5 && args.sync) {
+        // the cohort: 32 consecutive positions of one XCD label; how many of them hold a tile (as in gram_tile_of, 8 x 8 groups)
+        const uint32_t lb = blockIdx.x - (uint32_t)J.block_begin, seq = lb >> 3, xcd = lb & 7u;
+        const uint32_t live = (uint32_t)J.live, full = live >> 9;
+        sync_members = 32;
+        if ((seq >> 6) >= full) {
+            const uint32_t rest = live - (full << 9), chunk = (rest + 7u) >> 3;
+            const uint32_t first = (seq - (full << 6)) & ~31u;
+            const uint32_t mine = min(chunk, rest > xcd * chunk ? rest - xcd * chunk : 0u);
+            sync_members = mine > first ? min(32u, mine - first) : 0u;
+        }
+        sync_cnt = args.sync + (((int64_t)blockIdx.x >> 8) * 8 + (blockIdx.x & 7));
     }
     auto meet = [&](int limit) __attribute__((always_inline)) {
         if (threadIdx.x == 0) {
@@ -833,7 +936,7 @@ gram_ring_kernel(GramArgs args) {
     for (int s = 0; s < NST - 1; ++s)
 #pragma unroll
         for (int e = 0; e < NE; ++e) dma(s, (uint32_t)min(s, lastst) * 128u, e);
-    wait_next_stage();   // here: stage 0
+    [[maybe_unused]] const uint64_t t_issued = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
 
     const int frag_k = lane >> 4, frag_r = lane & 15;
     typedef const __attribute__((address_space(3))) v2d* lfrag_t;
@@ -853,7 +956,6 @@ gram_ring_kernel(GramArgs args) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) b[n] = *(lfrag_t)(size_t)(fb[kk] + (uint32_t)(buf * STAGE + n * 2048));
     };
-    read_frags(0, 0);
 
     // stage hh out of buffer S; the DMA of stage hh + NST - 1 goes into buffer S - 1 (mod NST), which every wave
     // left behind at the last barrier.  Past the end the DMA re-reads the last stage into a buffer nobody reads
@@ -900,8 +1002,18 @@ gram_ring_kernel(GramArgs args) {
         }
     };
     using std::integral_constant;
-    int h = 0;
     const int meet_mask = (1 << args.sync_shift) - 1;
+    wait_next_stage();   // here: stage 0
+    if constexpr ((QK_GRAM_ABLATE & 128) != 0) t_first = wall_clock64();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[c][m][n] = (v4d){0, 0, 0, 0};
+    read_frags(0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    int h = 0;
     for (int trip = 1; h + NST <= stages; h += NST, ++trip) {
         if (sync_cnt && (trip & meet_mask) == 0) meet(40);      // scalar test; the other waves meet thread 0 at the next barrier
         stage(integral_constant<int, 0>{}, h);
@@ -919,7 +1031,22 @@ gram_ring_kernel(GramArgs args) {
         if (h + 2 < stages) stage(integral_constant<int, 2>{}, h + 2);
         if (h + 3 < stages) stage(integral_constant<int, 3>{}, h + 3);
     }
+    __builtin_amdgcn_s_setprio(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be writing this workgroup's LDS when it ends
+    if constexpr ((QK_GRAM_ABLATE & 128) != 0) {   // timeline build, as in gram_lean_kernel
+        const uint64_t t_loop = wall_clock64();
+        gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t t_end = wall_clock64();
+        if (tid == 0 && args.trace) {
+            double* o = args.trace + (int64_t)blockIdx.x * 8;
+            o[0] = (double)t_start; o[1] = (double)t_first; o[2] = (double)t_loop; o[3] = (double)t_end;
+            o[4] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+            o[5] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+            o[6] = (double)t_located; o[7] = (double)t_issued;   // (the lean kernel leaves ti, tj here)
+        }
+        return;
+    }
     gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
 }
 
@@ -970,7 +1097,7 @@ gram32_dma_kernel(GramArgs args) {
     extern __shared__ v4f smem32[];
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, J, ti, tj)) return;
+    if (!gram_locate(args, (int64_t)blockIdx.x, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
 
     const int tid = threadIdx.x;
@@ -1127,7 +1254,8 @@ gram32_ring_kernel(GramArgs args) {
     extern __shared__ v4f smem32[];
     GramJobDev J;
     int ti, tj;
-    if (!gram_locate(args, J, ti, tj)) return;
+    __builtin_amdgcn_s_setprio(3);   // as in gram_ring_kernel: raised priority outside the stage loop
+    if (!gram_locate(args, (int64_t)blockIdx.x, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
 
     const int tid = threadIdx.x;
@@ -1266,6 +1394,7 @@ gram32_ring_kernel(GramArgs args) {
         if (((hh + 1) & (FLUSH - 1)) == 0) flush();
     };
     using std::integral_constant;
+    __builtin_amdgcn_s_setprio(0);
     int h = 0;
     for (; h + NST <= stages; h += NST) {
         stage(integral_constant<int, 0>{}, h);
@@ -1282,6 +1411,7 @@ gram32_ring_kernel(GramArgs args) {
         if (h + 2 < stages) stage(integral_constant<int, 2>{}, h + 2);
         if (h + 3 < stages) stage(integral_constant<int, 3>{}, h + 3);
     }
+    __builtin_amdgcn_s_setprio(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     flush();
     gram32_epilogue<TM, TN>(hre, him, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
@@ -1452,6 +1582,7 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
     for (int k = 0; k < n_jobs; ++k) {
         const qk_gram_job& j = jobs[k];
         if (j.ma < 0 || j.nb < 0) return fail(QK_ERR_INVALID, std::string(who) + ": negative block size");
+        if (j.ma > 0x7fffffffLL || j.nb > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, std::string(who) + ": more than 2^31 - 1 rows in a block");
         if (j.ma == 0 || j.nb == 0) continue;
         if (!j.A || !j.B || !j.K) return fail(QK_ERR_INVALID, std::string(who) + ": null pointer in job");
         if (j.ldk < j.nb || (j.KT && j.ldkt < j.ma))

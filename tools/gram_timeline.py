@@ -49,6 +49,10 @@ out = {"rows": N, "qubits": n, "event_ms": ms, "workgroups": int(len(t)), "span_
        "loop_us_p90": float(np.percentile(us[:, 2] - us[:, 1], 90)),
        "epilogue_us_med": float(np.median(us[:, 3] - us[:, 2])), "epilogue_us_p90": float(np.percentile(us[:, 3] - us[:, 2], 90)),
        "tile_us_med": float(np.median(dur))}
+if t[:, 6].min() > 1e6:   # ring kernel: two more stamps inside the prologue
+    out["locate_us_med"] = float(np.median(t[:, 6] - t[:, 0]) / 100.0)
+    out["aim_and_issue_us_med"] = float(np.median(t[:, 7] - t[:, 6]) / 100.0)
+    out["first_data_us_med"] = float(np.median(t[:, 1] - t[:, 7]) / 100.0)
 # per CU: busy = union of workgroup intervals; gaps between a workgroup's end and the next start on the same CU
 gaps = []
 per_cu_tiles = []
