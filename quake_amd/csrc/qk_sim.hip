@@ -24,8 +24,8 @@
 namespace qk {
 
 struct SimArgs {
-    const double* X;
-    int64_t ldx;
+    const double2* cs;   // (cos, sin) of every gate angle of the pass, [n_expr][N] (angle_table_kernel)
+    int64_t N;
     double2* psi;   // may be null in fused-RDM mode (the statevectors are never written)
     float2* psi32;  // FP32 output (qk_simulate_c64_dev): the state is evolved in FP64 and rounded once, at the store
     double* rdm;    // fused mode: N x n x 4 reduced density matrices, computed from LDS (single chunk per sample)
@@ -36,12 +36,10 @@ struct SimArgs {
     const DevMat* mats;
     const DevComp* comps;    // composite matrices of the pass and their factor lists (pass-local matrix indices)
     const int32_t* facts;
-    int n_comp;
-    const qk_instr* prog;
-    const double* consts;
+    int n_comp, n_fact;
     int n_stage, n_expr, n_mat, n_term;
-    int n_prog, n_consts, n_params, staged;   // staged: exprs / prog / consts are copied to LDS
-    int red_off;                               // fused-RDM scratch: offset in doubles from the end of xbuf
+    int staged;                                // the pass's DevExpr records (destinations of the angles) are copied to LDS
+    int red_off;                               // fused-RDM scratch: offset in doubles from the end of the phase tables
     int L, h, lgT, n_qubits, first;
     uint32_t zero_in, zero_out;  // virtual-bit masks of still-|0> qubits (see Pass)
     int n_init;                  // first pass: leading ST_INIT stages (hoisted first gates)
@@ -81,13 +79,15 @@ __device__ __forceinline__ double2 cfma(double2 a, double2 b, double2 c) {  // a
 __device__ __forceinline__ uint32_t deposit(uint32_t w, const SimArgs& a) {
     uint32_t g = 0;
     // not unrolled: the unrolled form's trip-count tests ("one run?", "odd number?") are hoisted out of the item
-    // loop as booleans the register allocator then keeps in scratch memory (see the note at the item loop's head)
+    // loop as booleans the register allocator then keeps in scratch memory (see the note at the item loop's head);
+    // for the same reason the loop has no entry test (a pass always has at least one run)
+    int r = 0;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (int r = 0; r < a.nruns; ++r) {
+    do {
         const uint32_t m = w & a.run_mask[r];
         const int sh = a.run_shift[r];
         g |= sh >= 0 ? (m << sh) : (m >> (-sh));
-    }
+    } while (++r < a.nruns);
     return g;
 }
 
@@ -114,29 +114,118 @@ __device__ __forceinline__ void apply_term(const RTerm& t, uint32_t w, double& f
     }
 }
 
-template <int NG>
-__device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, const DevMat* mats, const DevStage& st,
+// The planner's tables (stages, matrix kinds) are written by the host before the launch and never by a kernel.  Read
+// through the constant address space with wave-uniform indices they come in over the scalar data path (s_load,
+// counted by lgkmcnt).  As ordinary global reads they were vector loads, and the s_waitcnt vmcnt(0) in front of
+// their first use also sat out every store of the previous item still on its way to HBM -- the drain the item loop
+// is arranged to compute under.
+#define QK_CONST_AS __attribute__((address_space(4)))
+typedef const int32_t QK_CONST_AS* ConstWords;
+__device__ __forceinline__ ConstWords const_words(const void* p) { return (ConstWords)(uintptr_t)p; }
+
+__device__ __forceinline__ DevStage load_stage(ConstWords stages, int idx) {
+    static_assert(sizeof(DevStage) == 24 * sizeof(int32_t), "DevStage is read word by word");
+    ConstWords w = stages + idx * 24;
+    DevStage st;
+    st.kind = w[0]; st.va = w[1]; st.vb = w[2]; st.ng = w[3];
+#pragma unroll
+    for (int k = 0; k < kMaxGroup; ++k) { st.gv[k] = w[4 + k]; st.gm[k] = w[4 + kMaxGroup + k]; }
+    st.t0 = w[10]; st.nLo = w[11]; st.nHi = w[12]; st.nX = w[13];
+#pragma unroll
+    for (int k = 0; k <= kMaxRowBits; ++k) st.xo[k] = w[14 + k];
+    st.nLoD = w[22]; st.nHiD = w[23];
+    return st;
+}
+constexpr int kStageXoWord = 14;     // offset of DevStage::xo in words
+
+// The factor of one diagonal term as a complex number, (1, 0) where the term does not act: no branches.
+__device__ __forceinline__ double2 term_factor(const RTerm& t, uint32_t w) {
+    const uint32_t ba = (w >> t.va) & 1u, bb = (w >> t.vb) & 1u;
+    const bool rz = t.type == TM_RZ;
+    const bool on = rz || (t.type == TM_P ? ba != 0u : (t.type == TM_CZ ? (ba & bb) != 0u : (ba ^ bb) != 0u));
+    const double s = (rz && !ba) ? -t.s : t.s;
+    return make_double2(on ? t.c : 1.0, on ? s : 0.0);
+}
+
+// f *= the factors of terms t[0 .. n) at index w.  The phase tables are built by a few threads per sample while the
+// rest of the workgroup waits, so what counts is the length of the dependent chain: the terms of four steps are read
+// together (their LDS reads are independent of the products) and the product runs as two chains.
+__device__ __forceinline__ void apply_terms(const RTerm* t, int n, uint32_t w, double& fr, double& fi) {
+    double2 p = make_double2(fr, fi), q = make_double2(1.0, 0.0);
+    int k = 0;
+    for (; k + 3 < n; k += 4) {
+        const RTerm t0 = t[k], t1 = t[k + 1], t2 = t[k + 2], t3 = t[k + 3];
+        p = cmul(p, term_factor(t0, w));
+        q = cmul(q, term_factor(t1, w));
+        p = cmul(p, term_factor(t2, w));
+        q = cmul(q, term_factor(t3, w));
+    }
+    for (; k < n; ++k) p = cmul(p, term_factor(t[k], w));
+    p = cmul(p, q);
+    fr = p.x;
+    fi = p.y;
+}
+
+// f *= the product-state factors of the hoisted first gates whose bit lies in one half of the local bits
+// (is_lo: virtual bits < h; else h <= bit < L), for the amplitude index w; reads batched as in apply_terms
+__device__ __forceinline__ double2 init_factors(const int2* s_init, int n_init, const double2* mat, int L, int h, bool is_lo,
+                                                uint32_t w, double2 f) {
+    double2 q = make_double2(1.0, 0.0);
+    const double2 one = make_double2(1.0, 0.0);
+    auto use = [&](int2 g) { return g.x < L && (g.x < h) == is_lo; };
+    auto at = [&](int2 g) { return 4 * g.y + 2 * (int)((w >> (g.x & 31)) & 1u); };
+    int k = 0;
+    for (; k + 3 < n_init; k += 4) {
+        const int2 g0 = s_init[k], g1 = s_init[k + 1], g2 = s_init[k + 2], g3 = s_init[k + 3];
+        const double2 m0 = mat[at(g0)], m1 = mat[at(g1)], m2 = mat[at(g2)], m3 = mat[at(g3)];
+        f = cmul(f, use(g0) ? m0 : one);
+        q = cmul(q, use(g1) ? m1 : one);
+        f = cmul(f, use(g2) ? m2 : one);
+        q = cmul(q, use(g3) ? m3 : one);
+    }
+    for (; k < n_init; ++k) {
+        const int2 g = s_init[k];
+        const double2 m = mat[at(g)];
+        f = cmul(f, use(g) ? m : one);
+    }
+    return cmul(f, q);
+}
+
+// a wave-uniform double as a scalar-register pair (values read from LDS arrive in vector registers)
+__device__ __forceinline__ double uniform_f64(double x) {
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+template <int NG, int IPT>
+__device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, ConstWords mats, const DevStage& st,
                                          uint32_t nloc, int tid, int T) {
     // NG single-qubit gates on distinct local qubits in one sweep: each thread holds the 2^NG
     // amplitudes that differ in the target bits and applies the gates in registers.
     // form: 0 = real matrix (x, ry), 1 = real diagonal + imaginary off-diagonal (rx), 2 = general (sx),
     //       3 = hadamard (adds only; the factors 1/sqrt 2 of the group are applied once at the end)
     // The 2^NG amplitude offsets depend on the stage only (wave-uniform: scalar registers), so an item costs
-    // NG bit insertions and one OR per amplitude.  (An XOR-swizzled register mapping that removed the LDS bank
-    // conflicts of low target bits made the offsets per-lane values and bought no time: the sweeps are bound
-    // by VALU issue, not by LDS.)
+    // NG bit insertions and one OR per amplitude.
+    // The workgroup runs two waves per SIMD at most (LDS holds two states per CU), so nothing hides the latency of
+    // an LDS read but the thread's own independent work: a trip handles IPT items and issues all of their reads
+    // before the first butterfly.  The matrices are wave-uniform and sit in scalar registers (they come out of
+    // LDS as vector registers: 48 of them in a radix-8 sweep, which is what made two items per trip spill).
     double2 m[NG][4];
     uint32_t lm[NG], off[1 << NG];
     int form[NG];
-    double hscale = 1.0;
+    int nh = 0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m[g][k] = mat[4 * st.gm[g] + k];
-        lm[g] = (1u << st.gv[g]) - 1u;
-        const int gate = mats[st.gm[g]].gate;
+        const int gate = mats[2 * st.gm[g]];      // DevMat::gate
         form[g] = gate == QK_H ? 3 : ((gate == QK_X || gate == QK_RY) ? 0 : (gate == QK_RX ? 1 : 2));
-        if (gate == QK_H) hscale *= 0.70710678118654752440;
+        nh += gate == QK_H ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double2 e = mat[4 * st.gm[g] + k];
+            m[g][k] = make_double2(uniform_f64(e.x), uniform_f64(e.y));
+        }
+        lm[g] = (1u << st.gv[g]) - 1u;
     }
 #pragma unroll
     for (int k = 0; k < (1 << NG); ++k) {
@@ -145,6 +234,8 @@ __device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, con
         for (int g = 0; g < NG; ++g) o |= (((uint32_t)k >> g) & 1u) << st.gv[g];
         off[k] = o;
     }
+    // 2^(-nh/2), chosen among constants (a running product of 1/sqrt 2 ends up as a vector register the allocator spills)
+    const double hscale = nh == 1 ? 0.70710678118654752440 : (nh == 2 ? 0.5 : (nh == 3 ? 0.35355339059327376220 : 1.0));
     auto base_of = [&](uint32_t i) {
         uint32_t b = i;
 #pragma unroll
@@ -193,56 +284,76 @@ __device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, con
                     }
             }
         }
-        if (hscale != 1.0) {
+        if (nh != 0) {
 #pragma unroll
             for (int k = 0; k < (1 << NG); ++k) v[k] = make_double2(v[k].x * hscale, v[k].y * hscale);
         }
     };
-    const uint32_t items = nloc >> NG;
-    uint32_t i = tid;
-    // (Two items per trip, the second one's LDS reads in flight while the first is computed, was tried: the extra
-    // 64 registers spill in the radix-8 kernel and the sweep gets slower, 6.8 -> 7.9 ms on ZZ r = 2 at 16 qubits.)
-    for (; i < items; i += T) {
-        const uint32_t b = base_of(i);
-        double2 v[1 << NG];
+    const uint32_t items = nloc >> NG;     // a power of two, like T: every trip of the loop is full or not taken
+    for (uint32_t i = tid; i < items; i += IPT * T) {
+        uint32_t b[IPT];
+        double2 v[IPT][1 << NG];
 #pragma unroll
-        for (int k = 0; k < (1 << NG); ++k) v[k] = state[b | off[k]];
-        butterflies(v);
+        for (int p = 0; p < IPT; ++p) b[p] = base_of(i + p * T);
 #pragma unroll
-        for (int k = 0; k < (1 << NG); ++k) state[b | off[k]] = v[k];
+        for (int p = 0; p < IPT; ++p)
+#pragma unroll
+            for (int k = 0; k < (1 << NG); ++k) v[p][k] = state[b[p] | off[k]];
+#pragma unroll
+        for (int p = 0; p < IPT; ++p) butterflies(v[p]);
+#pragma unroll
+        for (int p = 0; p < IPT; ++p)
+#pragma unroll
+            for (int k = 0; k < (1 << NG); ++k) state[b[p] | off[k]] = v[p][k];
     }
 }
 
-// The per-sample gate angles: one thread per angle runs its postfix program (validated on the
-// host: qk_circuit_create) and leaves (cos, sin) in the diagonal term or the 2x2 matrix it feeds.
-// Called once with the tables staged in LDS and once with them in global memory, so each copy
-// is compiled for one address space.
-template <class ExprPtr, class ProgPtr, class ConstPtr>
-__device__ __forceinline__ void run_angle_programs(ExprPtr exprs, ProgPtr prog, ConstPtr consts, const double* xrow,
-                                                   int n_expr, RTerm* rt, double2* mat, int tid, int T) {
-    for (int e = tid; e < n_expr; e += T) {
-        const DevExpr ex = exprs[e];
-        const double angle = run_postfix(prog, ex.start, ex.len, consts, xrow);
-        double sn, cn;
-        sincos_cw(angle * ex.scale, &sn, &cn);   // the routine the wave-resident kernel uses: one set of angles per circuit
-        if (ex.dst >= 0) {
-            rt[ex.dst].c = cn;
-            rt[ex.dst].s = sn;
-        } else {  // rx / ry / rz from cos, sin of theta/2, p from those of lambda (rz, p: only as factors of a composite)
-            const int m = ~ex.dst;
-            if (ex.gate == QK_RX) {
-                mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(0, -sn);
-                mat[4 * m + 2] = make_double2(0, -sn); mat[4 * m + 3] = make_double2(cn, 0);
-            } else if (ex.gate == QK_RZ) {
-                mat[4 * m + 0] = make_double2(cn, -sn); mat[4 * m + 1] = make_double2(0, 0);
-                mat[4 * m + 2] = make_double2(0, 0); mat[4 * m + 3] = make_double2(cn, sn);
-            } else if (ex.gate == QK_P) {
-                mat[4 * m + 0] = make_double2(1, 0); mat[4 * m + 1] = make_double2(0, 0);
-                mat[4 * m + 2] = make_double2(0, 0); mat[4 * m + 3] = make_double2(cn, sn);
-            } else {
-                mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(-sn, 0);
-                mat[4 * m + 2] = make_double2(sn, 0); mat[4 * m + 3] = make_double2(cn, 0);
-            }
+template <int NG>
+__device__ __forceinline__ void sweep_u1_any(double2* state, const double2* mat, ConstWords mats, const DevStage& st,
+                                             uint32_t nloc, int tid, int T) {
+    if ((nloc >> NG) >= 2u * (uint32_t)T) sweep_u1<NG, 2>(state, mat, mats, st, nloc, tid, T);
+    else sweep_u1<NG, 1>(state, mat, mats, st, nloc, tid, T);
+}
+
+// The per-sample gate angles.  A pre-pass (angle_table_kernel) evaluates them for all samples, one LANE per sample:
+// every lane of a wave runs the same postfix program (validated on the host: qk_circuit_create) on its own feature
+// row, so the interpreter's control flow is uniform and 64 samples share each of its instructions -- inside the
+// simulator the same work was one thread per angle of ONE sample, a single wave of lanes diverging over the
+// interpreter's switch while the rest of the workgroup waited (3 us of a 31 us item for the ZZ map at 12 qubits, 9 us
+// for a GA genome with its asin: tools/sim_trace.py).  The table holds (cos, sin) of angle * scale as [expr][sample].
+__global__ void __launch_bounds__(256) angle_table_kernel(const DevExpr* exprs, int n_expr, const qk_instr* prog,
+                                                          const double* consts, const double* X, int64_t ldx, int64_t N,
+                                                          double2* cs) {
+    // a wave = 64 consecutive samples x one angle (blockIdx.y * 4 + wave): small batches still fill the chip
+    const int e = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+    const int64_t smp = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (e >= n_expr || smp >= N) return;
+    const int start = __builtin_amdgcn_readfirstlane(exprs[e].start), len = __builtin_amdgcn_readfirstlane(exprs[e].len);
+    const double angle = run_postfix(prog, start, len, consts, X + smp * ldx);
+    double sn, cn;
+    sincos_cw(angle * exprs[e].scale, &sn, &cn);   // the routine the wave-resident kernel uses: one set of angles per circuit
+    cs[(int64_t)e * N + smp] = make_double2(cn, sn);
+}
+
+// (cos, sin) of one angle into the diagonal term or the 2x2 matrix it feeds
+__device__ __forceinline__ void scatter_angle(const DevExpr& ex, double cn, double sn, RTerm* rt, double2* mat) {
+    if (ex.dst >= 0) {
+        rt[ex.dst].c = cn;
+        rt[ex.dst].s = sn;
+    } else {  // rx / ry / rz from cos, sin of theta/2, p from those of lambda (rz, p: only as factors of a composite)
+        const int m = ~ex.dst;
+        if (ex.gate == QK_RX) {
+            mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(0, -sn);
+            mat[4 * m + 2] = make_double2(0, -sn); mat[4 * m + 3] = make_double2(cn, 0);
+        } else if (ex.gate == QK_RZ) {
+            mat[4 * m + 0] = make_double2(cn, -sn); mat[4 * m + 1] = make_double2(0, 0);
+            mat[4 * m + 2] = make_double2(0, 0); mat[4 * m + 3] = make_double2(cn, sn);
+        } else if (ex.gate == QK_P) {
+            mat[4 * m + 0] = make_double2(1, 0); mat[4 * m + 1] = make_double2(0, 0);
+            mat[4 * m + 2] = make_double2(0, 0); mat[4 * m + 3] = make_double2(cn, sn);
+        } else {
+            mat[4 * m + 0] = make_double2(cn, 0); mat[4 * m + 1] = make_double2(-sn, 0);
+            mat[4 * m + 2] = make_double2(sn, 0); mat[4 * m + 3] = make_double2(cn, 0);
         }
     }
 }
@@ -256,6 +367,11 @@ __device__ __forceinline__ void run_angle_programs(ExprPtr exprs, ProgPtr prog, 
 // then sat out the drain of the previous item's stores -- about 10 us of a 17-37 us item at 12 qubits
 // (tools/sim_trace.py) -- instead of computing under it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The batched loops below name their in-flight values one by one: as arrays (even fully unrolled ones) they stay in
+// scratch memory in this kernel -- the backend's alloca promotion has no register budget left at 256 VGPRs.
+#define QK_REP4(M) M(0) M(1) M(2) M(3)
+#define QK_REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 
 template <int MAXG, bool RDM>
 __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 : 3) sim_pass_kernel(SimArgs a) {
@@ -273,15 +389,16 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     // sample): it IS tlo / thi
     double2* blo = a.hoist == 2 ? tables_end : tlo;
     double2* bhi = a.hoist == 2 ? blo + (1u << h) : thi;
-    double* xbuf = a.hoist == 2 ? (double*)(bhi + (1u << (L - h))) : (double*)tables_end;   // feature rows of this item and the next
-    const int xs = (a.n_params + 1) & ~1;
-    DevExpr* s_expr = (DevExpr*)(xbuf + 2 * xs);            // staged angle programs (a.staged)
-    qk_instr* s_prog = (qk_instr*)(s_expr + a.n_expr);
-    double* s_const = (double*)(s_prog + a.n_prog);
-    int2* s_init = (int2*)(s_const + a.n_consts);           // (virtual bit, matrix) of the hoisted first gates
-    double* s_red = (double*)(xbuf + 2 * xs) + a.red_off;   // fused-RDM partial sums
+    double* after_tables = a.hoist == 2 ? (double*)(bhi + (1u << (L - h))) : (double*)tables_end;
+    DevExpr* s_expr = (DevExpr*)after_tables;              // staged DevExpr records (a.staged)
+    int2* s_init = (int2*)(s_expr + (a.staged ? a.n_expr : 0));   // (virtual bit, matrix) of the hoisted first gates
+    DevComp* s_comp = (DevComp*)(s_init + a.n_init);       // composite matrices of the pass and their factor lists: read
+    int32_t* s_fact = (int32_t*)(s_comp + a.n_comp);       // per thread at the start of a sample (see const_words above)
+    double* s_red = after_tables + a.red_off;              // fused-RDM partial sums
     const int tid = threadIdx.x;
     const int T = blockDim.x;
+    static_assert(sizeof(DevMat) == 2 * sizeof(int32_t), "DevMat is read word by word");
+    const ConstWords c_stages = const_words(a.stages), c_mats = const_words(a.mats);
 
     // ---- once per workgroup: everything that does not depend on the sample -----------------
     for (int t = tid; t < a.n_term; t += T) {
@@ -305,26 +422,31 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         }
         mat[4 * m + 0] = m00; mat[4 * m + 1] = m01; mat[4 * m + 2] = m10; mat[4 * m + 3] = m11;
     }
-    if (!a.staged) s_init = (int2*)(xbuf + 2 * xs);
     for (int k = tid; k < a.n_init; k += T) s_init[k] = make_int2(a.stages[k].va, a.stages[k].gm[0]);
-    if (a.staged) {
+    if (a.staged)
         for (int e = tid; e < a.n_expr; e += T) s_expr[e] = a.exprs[e];
-        for (int k = tid; k < a.n_prog; k += T) s_prog[k] = a.prog[k];
-        for (int k = tid; k < a.n_consts; k += T) s_const[k] = a.consts[k];
-    }
+    for (int k = tid; k < a.n_comp; k += T) s_comp[k] = a.comps[k];
+    for (int k = tid; k < a.n_fact; k += T) s_fact[k] = a.facts[k];
     // Persistent workgroups: each owns a contiguous range of (sample, chunk) items, so the launch
     // cost is paid once per CU slot and the chunks of one sample follow each other: the angle
     // programs (the longest dependent chain of an item) run once per sample, not once per chunk.
     const int64_t per_wg = (a.n_items + gridDim.x - 1) / gridDim.x;
     const int64_t item_begin = (int64_t)blockIdx.x * per_wg;
     const int64_t item_end = item_begin + per_wg < a.n_items ? item_begin + per_wg : a.n_items;
-    if (item_begin < item_end)
-        for (int t = tid; t < a.n_params; t += T) xbuf[t] = a.X[(item_begin >> a.nlive) * a.ldx + t];
+    lds_barrier();
+    // the angles of the workgroup's first sample; every later sample's are fetched while the sample before it is
+    // computed and dealt out after its last stage
+    if (item_begin < item_end) {
+        for (int e = tid; e < a.n_expr; e += T) {
+            const double2 v = a.cs[(int64_t)e * a.N + (item_begin >> a.nlive)];
+            scatter_angle(a.staged ? s_expr[e] : a.exprs[e], v.x, v.y, rt, mat);
+        }
+    }
     lds_barrier();
 
     // Chunks whose amplitudes are all still zero after the pass (and a later pass knows) are not
     // items at all.  In steady state the only vector-memory traffic of a first pass is the store of
-    // the chunk and the prefetch of the next feature row, so the stores of one item drain while the
+    // the chunk and the prefetch of the next sample's angles, so the stores of one item drain while the
     // next is computed.
     // A diagonal stage right after the hoisted first gates (every Z / ZZ map) takes the product
     // state as two more factors of its tables: the state is written once, phases included.
@@ -336,8 +458,8 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     // the terms without a chunk bit, the cross-term ratios) is computed once per sample; a chunk
     // multiplies in its scalar and the few terms that read a chunk bit.
     const bool hoist = a.hoist != 0;    // = fuse_init, decided by the host with the LDS layout
-    int par = 0;
     int64_t angles_of = -1;     // the sample whose (cos, sin) values sit in rt / mat
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef QK_SIM_TRACE
     double tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 load + angles + tables, 1 product state, 2 diag tables, 3 diag sweep, 4 u1, 5 cx / ecr, 6 store, 7 items
     uint64_t tr_last = wall_clock64();
@@ -347,15 +469,23 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
     for (int64_t item = item_begin; item < item_end; ++item) {
         const int64_t next = item + 1;
         const bool fetch = next < item_end && (next >> a.nlive) != (item >> a.nlive);
-        // The addresses of the feature-row prefetch are recomputed per item from an opaque copy of the thread index:
+        // The addresses of the angle prefetch are recomputed per item from an opaque copy of the thread index:
         // hoisted out of the loop they end up spilled, and a reload from scratch memory at the top of an item
         // waits (memory operations return in order) for every store of the previous item -- the drain this loop
         // is built to compute under (10 us of a 17-37 us item at 12 qubits: tools/sim_trace.py).
-        int tid_x = tid;
+        // (the copy is rebuilt from the lane counter and the wave's number in a scalar register: held in a vector
+        // register across the loop, the thread index itself is what gets spilled)
+        uint32_t ones = ~0u;
+        asm volatile("" : "+s"(ones));
+        int tid_x = (wave_s << 6) | (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
         asm volatile("" : "+v"(tid_x));
-        const bool have_next = fetch && tid_x < a.n_params;
-        double xnext = 0.0;
-        if (have_next) xnext = a.X[(next >> a.nlive) * a.ldx + tid_x];   // in flight until the end of the item
+        // ... and for the same reason every per-thread index of an item is derived from that copy: whatever the
+        // compiler can prove invariant (column numbers, LDS addresses of this thread's table entries) it computes
+        // before the loop, keeps across it, and -- at 168 or 256 registers -- spills
+        const int tid = tid_x;
+        const bool have_next = fetch && tid_x < a.n_expr;
+        double2 cs_next = make_double2(1.0, 0.0);
+        if (have_next) cs_next = a.cs[(int64_t)tid_x * a.N + (next >> a.nlive)];   // in flight until the end of the item
         uint32_t chunk = 0;
         {
             uint32_t ci = (uint32_t)(item & ((1u << a.nlive) - 1u)), m = a.live_chunks;
@@ -363,7 +493,6 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 if (m & 1u) { chunk |= (ci & 1u) << b; ci >>= 1; }
         }
         const int64_t sample = item >> a.nlive;
-        const double* xrow = xbuf + par * xs;
         const uint32_t whi = chunk << L;
 
         // ---- chunk load -----------------------------------------------------------------
@@ -379,7 +508,19 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             if (whi & a.zero_in) {
                 for (uint32_t l = tid; l < nloc; l += T) state[l] = make_double2(0.0, 0.0);
             } else {
-                for (uint32_t l = tid; l < nloc; l += T)
+                // eight loads in flight per thread (the loop as written waits for each load before it issues the next
+                // one: the LDS store may alias nothing the compiler can see, but it keeps the order)
+                uint32_t l = tid;
+                for (; l + 7u * T < nloc; l += 8u * T) {
+#define QK_LD(k) const uint32_t l##k = l + k##u * T; \
+                 const double2 v##k = (l##k & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | deposit(l##k, a)];
+#define QK_ST(k) state[l##k] = v##k;
+                    QK_REP8(QK_LD)
+                    QK_REP8(QK_ST)
+#undef QK_LD
+#undef QK_ST
+                }
+                for (; l < nloc; l += T)
                     state[l] = (l & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | deposit(l, a)];
             }
         }
@@ -388,17 +529,15 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         if (tid == 0) tr_pre += wall_clock64() - tr_last;
 #endif
         if (sample != angles_of) {
-            if (a.staged) run_angle_programs(s_expr, s_prog, s_const, xrow, a.n_expr, rt, mat, tid_x, T);
-            else run_angle_programs(a.exprs, a.prog, a.consts, xrow, a.n_expr, rt, mat, tid_x, T);
+            // (its angles are in place: dealt out before the loop or at the end of the previous sample's last item)
             angles_of = sample;
 #ifdef QK_SIM_TRACE
             if (tid == 0) tr_angles += wall_clock64() - tr_last;
 #endif
             if (a.n_comp) {     // runs of single-qubit gates on one qubit: one thread multiplies a run's factors
-                lds_barrier();
                 for (int k = tid_x; k < a.n_comp; k += T) {
-                    const DevComp cc = a.comps[k];
-                    const int32_t* f = a.facts + cc.first;
+                    const DevComp cc = s_comp[k];
+                    const int32_t* f = s_fact + cc.first;
                     double2 m0 = mat[4 * f[0]], m1 = mat[4 * f[0] + 1], m2 = mat[4 * f[0] + 2], m3 = mat[4 * f[0] + 3];
                     for (int j = 1; j < cc.count; ++j) {     // M <- G M
                         const double2* g = mat + 4 * f[j];
@@ -412,7 +551,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
             }
             if (hoist) {
                 lds_barrier();
-                const DevStage st = a.stages[a.n_init];
+                const DevStage st = load_stage(c_stages, a.n_init);
                 const RTerm* tl = rt + st.t0;
                 const RTerm* th = tl + st.nLo;
                 const RTerm* tx = th + st.nHi;
@@ -434,7 +573,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         const uint32_t c = j & (nlo - 1u);
                         const uint32_t ra = __builtin_amdgcn_readfirstlane(j >> h);
                         const uint32_t w1 = c | (1u << (h + ra));
-                        const int32_t* xo = a.stages[a.n_init].xo;
+                        ConstWords xo = c_stages + a.n_init * 24 + kStageXoWord;
                         double gr = 1.0, gi = 0.0;
                         for (int k = xo[ra]; k < xo[ra + 1]; ++k) {
                             apply_term(tx[k], w1, fr, fi);
@@ -447,17 +586,14 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         const uint32_t wl = is_lo ? e : (e << h);
                         const uint32_t w = all ? (whi | wl) : wl;
                         double2 f = (wl & a.zero_in) ? make_double2(0.0, 0.0) : (is_lo ? gs : make_double2(1.0, 0.0));
-                        for (int q = 0; q < a.n_init; ++q) {
-                            const int2 g = s_init[q];
-                            if (g.x < L && (g.x < h) == is_lo) f = cmul(f, mat[4 * g.y + 2 * ((w >> g.x) & 1u)]);
-                        }
+                        f = init_factors(s_init, a.n_init, mat, L, h, is_lo, w, f);
                         fr = f.x; fi = f.y;
                         if (is_lo) {
-                            for (int k = 0; k < n_tl; ++k) apply_term(tl[k], w, fr, fi);
-                            for (int k = 0; k < st.nX; ++k) apply_term(tx[k], w, fr, fi);   // X(0, c)
+                            apply_terms(tl, n_tl, w, fr, fi);
+                            apply_terms(tx, st.nX, w, fr, fi);   // X(0, c)
                             blo[e] = make_double2(fr, fi);
                         } else {
-                            for (int k = 0; k < n_th; ++k) apply_term(th[k], w, fr, fi);
+                            apply_terms(th, n_th, w, fr, fi);
                             bhi[e] = make_double2(fr, fi);
                         }
                     }
@@ -471,7 +607,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         // amplitude(w) = prod_q U_q[w_q][0] over the initialised qubits, 0 where a bit of an
         // uninitialised qubit is set; factored over the column / row halves like a diagonal stage
         if (a.hoist == 2) {
-            const DevStage st = a.stages[a.n_init];
+            const DevStage st = load_stage(c_stages, a.n_init);
             const RTerm* tld = rt + st.t0 + (st.nLo - st.nLoD);
             const RTerm* thd = rt + st.t0 + st.nLo + (st.nHi - st.nHiD);
             const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
@@ -485,10 +621,10 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 double2 f = is_lo ? cmul(blo[j], gs) : bhi[j - nlo];
                 const uint32_t w = whi | (is_lo ? j : ((j - nlo) << h));
                 if (is_lo) {
-                    for (int k = 0; k < st.nLoD; ++k) apply_term(tld[k], w, f.x, f.y);
+                    apply_terms(tld, st.nLoD, w, f.x, f.y);
                     tlo[j] = f;
                 } else {
-                    for (int k = 0; k < st.nHiD; ++k) apply_term(thd[k], w, f.x, f.y);
+                    apply_terms(thd, st.nHiD, w, f.x, f.y);
                     thi[j - nlo] = f;
                 }
             }
@@ -504,10 +640,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 const bool is_lo = j < nlo;
                 const uint32_t w = is_lo ? j : ((j - nlo) << h);
                 double2 f = (w & a.zero_in) ? make_double2(0.0, 0.0) : (is_lo ? gs : make_double2(1.0, 0.0));
-                for (int s = 0; s < a.n_init; ++s) {
-                    const int2 g = s_init[s];
-                    if (g.x < L && (g.x < h) == is_lo) f = cmul(f, mat[4 * g.y + 2 * ((w >> g.x) & 1u)]);
-                }
+                f = init_factors(s_init, a.n_init, mat, L, h, is_lo, w, f);
                 (is_lo ? tlo[j] : thi[j - nlo]) = f;
             }
             lds_barrier();
@@ -520,7 +653,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
         QK_MARK(1);
         // ---- stages -----------------------------------------------------------------------
         for (int s = a.first ? a.n_init : 0; s < a.n_stage; ++s) {
-            const DevStage st = a.stages[s];
+            const DevStage st = load_stage(c_stages, s);
             if (st.kind == ST_DIAG) {
                 // Local bits < h are the column c of an amplitude, the rest its row r:
                 //   phase(r, c) = tlo[c] * thi[r] * X(r, c),
@@ -544,7 +677,7 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         const uint32_t c = j & (nlo - 1u);
                         const uint32_t ra = __builtin_amdgcn_readfirstlane(j >> h);
                         const uint32_t w0 = whi | c, w1 = w0 | (1u << (h + ra));
-                        const int32_t* xo = a.stages[s].xo;   // from memory: indexing the register copy would spill it
+                        ConstWords xo = c_stages + s * 24 + kStageXoWord;   // from memory: indexing the register copy would spill it
                         double gr = 1.0, gi = 0.0;
                         for (int k = xo[ra]; k < xo[ra + 1]; ++k) {
                             apply_term(tx[k], w1, fr, fi);
@@ -554,12 +687,12 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                         rat[j] = make_double2(fma(fr, gr, fi * gi), fma(fi, gr, -(fr * gi)));
                     } else if (j < n_rat + nlo) {
                         const uint32_t c = j - n_rat, w = whi | c;
-                        for (int k = 0; k < st.nLo; ++k) apply_term(tl[k], w, fr, fi);
-                        for (int k = 0; k < st.nX; ++k) apply_term(tx[k], w, fr, fi);   // X(0, c)
+                        apply_terms(tl, st.nLo, w, fr, fi);
+                        apply_terms(tx, st.nX, w, fr, fi);   // X(0, c)
                         tlo[c] = fused ? cmul(tlo[c], make_double2(fr, fi)) : make_double2(fr, fi);
                     } else {
                         const uint32_t r = j - n_rat - nlo, w = whi | (r << h);
-                        for (int k = 0; k < st.nHi; ++k) apply_term(th[k], w, fr, fi);
+                        apply_terms(th, st.nHi, w, fr, fi);
                         thi[r] = fused ? cmul(thi[r], make_double2(fr, fi)) : make_double2(fr, fi);
                     }
                 }
@@ -590,33 +723,78 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                     if (kb > 1) rr1 = rat[(1u << h) | c];
                     if (kb > 2) rr2 = rat[(2u << h) | c];
                     if (kb > 3) rr3 = rat[(3u << h) | c];
-#pragma unroll 2
-                    for (uint32_t i = 0; i < rpw; ++i) {
-                        const uint32_t g = i ^ (i >> 1);
-                        if (i > 0) {
-                            const int b = __builtin_ctz(i);              // the bit that flips between gray(i-1) and gray(i)
-                            double2 q = b == 0 ? rr0 : (b == 1 ? rr1 : (b == 2 ? rr2 : rr3));
-                            if (!((g >> b) & 1u)) q.y = -q.y;            // bit cleared: divide = multiply by the conjugate
-                            X = cmul(X, q);
+                    if (kb >= 2 && !fused) {
+                        // Four rows at a time: X(r0 + i0 + j, c) = X(r0 + i0, c) * {1, rr0, rr1, rr0 rr1}[j].  The four
+                        // amplitudes, their row factors and the products are independent of each other, so the LDS reads
+                        // of a block are in flight together and the multiplications overlap -- with two waves per SIMD a
+                        // walk that updates X once per row (Gray code: one multiplication per amplitude) is a chain of
+                        // LDS and FP64 latencies nothing hides.  (The fused form below, which reads no amplitudes, keeps the walk:
+                        // measured, 4.9 vs 6.0 us per 12-qubit item.)
+                        const double2 rr01 = cmul(rr0, rr1);
+                        const uint32_t dep_c = to_hbm ? deposit(c, a) : 0u;
+                        for (uint32_t i0 = 0; i0 < rpw; i0 += 4) {
+                            const uint32_t r = r0 | i0;
+                            const double2 t0 = thi[r], t1 = thi[r + 1], t2 = thi[r + 2], t3 = thi[r + 3];
+                            const double2 s0 = state[(r << h) | c], s1 = state[((r + 1) << h) | c],
+                                          s2 = state[((r + 2) << h) | c], s3 = state[((r + 3) << h) | c];
+                            double2 Xb = X;
+                            if (i0 & 4u) Xb = cmul(Xb, rr2);
+                            if (i0 & 8u) Xb = cmul(Xb, rr3);
+                            double2 f0 = cmul(Xb, t0), f1 = cmul(cmul(Xb, rr0), t1), f2 = cmul(cmul(Xb, rr1), t2),
+                                    f3 = cmul(cmul(Xb, rr01), t3);
+                            f0 = cmul(s0, f0); f1 = cmul(s1, f1); f2 = cmul(s2, f2); f3 = cmul(s3, f3);
+                            if (to_hbm) {
+                                // deposit() is linear over disjoint bits: the column's part once per item, the row's part
+                                // wave-uniform
+#define QK_ST(j) { const int64_t at = chunk_phys | dep_c | deposit((r + j##u) << h, a); \
+                   if (a.psi32) (a.psi32 + sample * a.D)[at] = make_float2((float)f##j.x, (float)f##j.y); \
+                   else gpsi[at] = f##j; }
+                                QK_REP4(QK_ST)
+#undef QK_ST
+                            } else {
+                                state[(r << h) | c] = f0; state[((r + 1) << h) | c] = f1;
+                                state[((r + 2) << h) | c] = f2; state[((r + 3) << h) | c] = f3;
+                            }
                         }
-                        const uint32_t r = r0 | g;
-                        const double2 f = cmul(X, thi[r]);
-                        const uint32_t l = (r << h) | c;
-                        const double2 v = fused ? f : cmul(state[l], f);
-                        if (to_hbm) store_direct(l, v);
-                        else state[l] = v;
+                    } else {
+#pragma unroll 2
+                        for (uint32_t i = 0; i < rpw; ++i) {
+                            const uint32_t g = i ^ (i >> 1);
+                            if (i > 0) {
+                                const int b = __builtin_ctz(i);              // the bit that flips between gray(i-1) and gray(i)
+                                double2 q = b == 0 ? rr0 : (b == 1 ? rr1 : (b == 2 ? rr2 : rr3));
+                                if (!((g >> b) & 1u)) q.y = -q.y;            // bit cleared: divide = multiply by the conjugate
+                                X = cmul(X, q);
+                            }
+                            const uint32_t r = r0 | g;
+                            const double2 f = cmul(X, thi[r]);
+                            const uint32_t l = (r << h) | c;
+                            const double2 v = fused ? f : cmul(state[l], f);
+                            if (to_hbm) store_direct(l, v);
+                            else state[l] = v;
+                        }
                     }
                 }
             } else if (st.kind == ST_U1) {
-                if (st.ng == 1) sweep_u1<1>(state, mat, a.mats, st, nloc, tid, T);
-                else if (st.ng == 2) sweep_u1<2>(state, mat, a.mats, st, nloc, tid, T);
-                else if constexpr (MAXG >= 3) sweep_u1<3>(state, mat, a.mats, st, nloc, tid, T);
+                if (st.ng == 1) sweep_u1_any<1>(state, mat, c_mats, st, nloc, tid, T);
+                else if (st.ng == 2) sweep_u1_any<2>(state, mat, c_mats, st, nloc, tid, T);
+                else if constexpr (MAXG >= 3) sweep_u1_any<3>(state, mat, c_mats, st, nloc, tid, T);
             } else if (st.kind == ST_CX) {
                 const int vc = st.va, vt = st.vb;
                 if (vc >= L) {  // control is a chunk bit: X on the target, or nothing
                     if ((whi >> vc) & 1u) {
                         const uint32_t lowmask = (1u << vt) - 1u;
-                        for (uint32_t i = tid; i < (nloc >> 1); i += T) {
+                        uint32_t i = tid;
+                        for (; i + 3u * T < (nloc >> 1); i += 4u * T) {
+#define QK_LD(k) const uint32_t b##k = (((i + k##u * T) & ~lowmask) << 1) | ((i + k##u * T) & lowmask); \
+                 const double2 x##k = state[b##k], y##k = state[b##k | (1u << vt)];
+#define QK_ST(k) state[b##k] = y##k; state[b##k | (1u << vt)] = x##k;
+                            QK_REP4(QK_LD)
+                            QK_REP4(QK_ST)
+#undef QK_LD
+#undef QK_ST
+                        }
+                        for (; i < (nloc >> 1); i += T) {
                             const uint32_t i0 = ((i & ~lowmask) << 1) | (i & lowmask);
                             const uint32_t i1 = i0 | (1u << vt);
                             const double2 a0 = state[i0];
@@ -627,7 +805,18 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 } else {
                     const int lo = vc < vt ? vc : vt, hi = vc < vt ? vt : vc;
                     const uint32_t m_lo = (1u << lo) - 1u, m_hi = (1u << hi) - 1u;
-                    for (uint32_t i = tid; i < (nloc >> 2); i += T) {
+                    uint32_t i = tid;
+                    for (; i + 3u * T < (nloc >> 2); i += 4u * T) {     // four swaps in flight
+#define QK_LD(k) uint32_t b##k = (((i + k##u * T) & ~m_lo) << 1) | ((i + k##u * T) & m_lo); \
+                 b##k = (((b##k & ~m_hi) << 1) | (b##k & m_hi)) | (1u << vc); \
+                 const double2 x##k = state[b##k], y##k = state[b##k | (1u << vt)];
+#define QK_ST(k) state[b##k] = y##k; state[b##k | (1u << vt)] = x##k;
+                        QK_REP4(QK_LD)
+                        QK_REP4(QK_ST)
+#undef QK_LD
+#undef QK_ST
+                    }
+                    for (; i < (nloc >> 2); i += T) {
                         uint32_t b = ((i & ~m_lo) << 1) | (i & m_lo);
                         b = ((b & ~m_hi) << 1) | (b & m_hi);
                         const uint32_t i0 = b | (1u << vc);
@@ -642,25 +831,38 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 const int lo = v0 < v1 ? v0 : v1, hi = v0 < v1 ? v1 : v0;
                 const uint32_t m_lo = (1u << lo) - 1u, m_hi = (1u << hi) - 1u;
                 const double r = 0.70710678118654752440;
-                for (uint32_t i = tid; i < (nloc >> 2); i += T) {
-                    uint32_t b = ((i & ~m_lo) << 1) | (i & m_lo);
-                    b = ((b & ~m_hi) << 1) | (b & m_hi);
-                    const uint32_t j0 = b, j1 = b | (1u << v0), j2 = b | (1u << v1), j3 = j1 | (1u << v1);
-                    const double2 a0 = state[j0], a1 = state[j1], a2 = state[j2], a3 = state[j3];
-                    // 1/sqrt2 * [[0,1,0,i],[1,0,-i,0],[0,i,0,1],[-i,0,1,0]]
-                    state[j0] = make_double2(r * (a1.x - a3.y), r * (a1.y + a3.x));
-                    state[j1] = make_double2(r * (a0.x + a2.y), r * (a0.y - a2.x));
-                    state[j2] = make_double2(r * (a3.x - a1.y), r * (a3.y + a1.x));
-                    state[j3] = make_double2(r * (a2.x + a0.y), r * (a2.y - a0.x));
+                // 1/sqrt2 * [[0,1,0,i],[1,0,-i,0],[0,i,0,1],[-i,0,1,0]]
+#define QK_LD(k) uint32_t j##k = (((i + k##u * T) & ~m_lo) << 1) | ((i + k##u * T) & m_lo); \
+                 j##k = ((j##k & ~m_hi) << 1) | (j##k & m_hi); \
+                 const double2 p##k = state[j##k], q##k = state[j##k | (1u << v0)], u##k = state[j##k | (1u << v1)], \
+                               w##k = state[j##k | (1u << v0) | (1u << v1)];
+#define QK_ST(k) state[j##k] = make_double2(r * (q##k.x - w##k.y), r * (q##k.y + w##k.x)); \
+                 state[j##k | (1u << v0)] = make_double2(r * (p##k.x + u##k.y), r * (p##k.y - u##k.x)); \
+                 state[j##k | (1u << v1)] = make_double2(r * (w##k.x - q##k.y), r * (w##k.y + q##k.x)); \
+                 state[j##k | (1u << v0) | (1u << v1)] = make_double2(r * (u##k.x + p##k.y), r * (u##k.y - p##k.x));
+                uint32_t i = tid;
+                for (; i + T < (nloc >> 2); i += 2u * T) {     // two items in flight
+                    QK_LD(0) QK_LD(1)
+                    QK_ST(0) QK_ST(1)
                 }
+                for (; i < (nloc >> 2); i += T) {
+                    QK_LD(0)
+                    QK_ST(0)
+                }
+#undef QK_LD
+#undef QK_ST
             }
             lds_barrier();
             QK_MARK(st.kind == ST_DIAG ? 3 : (st.kind == ST_U1 ? 4 : 5));
         }
         // ---- write back (amplitudes that are still known-zero are left to the next pass) ------
-        if (have_next) xbuf[(par ^ 1) * xs + tid_x] = xnext;
-        if (fetch)   // more features than threads: the rest without the register detour
-            for (int t = tid_x + T; t < a.n_params; t += T) xbuf[(par ^ 1) * xs + t] = a.X[(next >> a.nlive) * a.ldx + t];
+        // the next sample's angles: every stage of this item is behind a barrier, its terms and matrices are free
+        if (have_next) scatter_angle(a.staged ? s_expr[tid_x] : a.exprs[tid_x], cs_next.x, cs_next.y, rt, mat);
+        if (fetch)   // more angles than threads: the rest without the register detour
+            for (int e = tid_x + T; e < a.n_expr; e += T) {
+                const double2 v = a.cs[(int64_t)e * a.N + (next >> a.nlive)];
+                scatter_angle(a.staged ? s_expr[e] : a.exprs[e], v.x, v.y, rt, mat);
+            }
         lds_barrier();
         if constexpr (RDM) rdm1_from_lds(state, L, s_red, a.rdm + sample * (L * 4), tid, T);
         if (a.direct || a.last_direct) {
@@ -672,13 +874,21 @@ __global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 
                 g32[chunk_phys | deposit(l, a)] = make_float2((float)v.x, (float)v.y);
             }
         } else if (!RDM || a.psi) {
-            for (uint32_t l = tid; l < nloc; l += T)
+            uint32_t l = tid;
+            for (; l + 7u * T < nloc; l += 8u * T) {
+#define QK_LD(k) const double2 v##k = state[l + k##u * T];
+#define QK_ST(k) if (!((l + k##u * T) & a.zero_out)) gpsi[chunk_phys | deposit(l + k##u * T, a)] = v##k;
+                QK_REP8(QK_LD)
+                QK_REP8(QK_ST)
+#undef QK_LD
+#undef QK_ST
+            }
+            for (; l < nloc; l += T)
                 if (!(l & a.zero_out)) gpsi[chunk_phys | deposit(l, a)] = state[l];
         }
         // LDS is reused by the next item.  A bare barrier: every wave's LDS reads have returned
         // before it issued its stores, and the stores themselves need not have landed.
         __builtin_amdgcn_s_barrier();
-        if (fetch) par ^= 1;
         QK_MARK(6);
 #ifdef QK_SIM_TRACE
         if (tid == 0) tr_acc[7] += 1.0;
@@ -797,12 +1007,42 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         QK_HIP(hipFuncSetAttribute((const void*)sim_pass_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
+    // the gate angles of all samples, every pass's at once (angle_table_kernel); the table lives in stream order
+    double2* cs_dev = nullptr;
+    const int n_expr_all = (int)c.exprs.size();
+    if (n_expr_all > 0) {
+        if ((N + 63) / 64 > 0x7fffffff) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
+        // the device's default pool hands freed memory back to the driver at the next synchronisation unless told to
+        // keep it: without this every call pays a driver allocation (0.1 ms) for its table
+        static DeviceOnce pool_set;
+        if (pool_set.pending()) {
+            int dev = 0;
+            hipMemPool_t pool = nullptr;
+            QK_HIP(hipGetDevice(&dev));
+            QK_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
+            uint64_t keep = ~0ull;
+            QK_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+            pool_set.done();
+        }
+        QK_HIP(hipMallocAsync((void**)&cs_dev, (size_t)n_expr_all * (size_t)N * sizeof(double2), (hipStream_t)stream));
+        hipLaunchKernelGGL(angle_table_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((n_expr_all + 3) / 4)), dim3(256), 0,
+                           (hipStream_t)stream, dt.exprs, n_expr_all, dt.prog, dt.consts, X_dev, ldx, N, cs_dev);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            (void)hipFreeAsync(cs_dev, (hipStream_t)stream);
+            return fail(QK_ERR_HIP, std::string("angle_table_kernel: ") + hipGetErrorString(e));
+        }
+    }
+    struct FreeCs {      // released in stream order once the passes below have been enqueued (or on an early return)
+        double2* p; hipStream_t s;
+        ~FreeCs() { if (p) (void)hipFreeAsync(p, s); }
+    } free_cs{cs_dev, (hipStream_t)stream};
     for (size_t pi = 0; pi < c.passes.size(); ++pi) {
         const Pass& ps = c.passes[pi];
         SimArgs a{};
         a.psi32 = (psi32_dev && pi + 1 == c.passes.size()) ? (float2*)psi32_dev : nullptr;
-        a.X = X_dev;
-        a.ldx = ldx;
+        a.cs = cs_dev ? cs_dev + (size_t)ps.expr_off * (size_t)N : nullptr;
+        a.N = N;
         a.psi = (double2*)psi_dev;
         a.rdm = rdm_dev;
         a.D = (int64_t)1 << n;
@@ -816,15 +1056,11 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.comps = dt.comps + ps.comp_off;
         a.facts = dt.facts + ps.fact_off;
         a.n_comp = ps.n_comp;
-        a.prog = dt.prog;
-        a.consts = dt.consts;
+        a.n_fact = (int)((pi + 1 < c.passes.size() ? c.passes[pi + 1].fact_off : (int)c.facts.size()) - ps.fact_off);
         a.n_stage = ps.n_stage;
         a.n_expr = ps.n_expr;
         a.n_mat = ps.n_mat;
         a.n_term = ps.n_term;
-        a.n_prog = (int)c.prog.size();
-        a.n_consts = (int)c.consts.size();
-        a.n_params = c.n_params;
         a.L = ps.L;
         a.h = ps.h;
         a.lgT = ps.lgT;
@@ -852,17 +1088,17 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
                          c.stages[ps.stage_off + ps.n_stage - 1].kind == ST_DIAG) ? 1 : 0;
         size_t lds = (direct ? (size_t)0 : ((size_t)16 << ps.L)) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
                      (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
-                     (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1) +
-                     (size_t)8 * ps.n_init;
-        const size_t stage_bytes = sizeof(DevExpr) * ps.n_expr + sizeof(qk_instr) * c.prog.size() + 8 * c.consts.size();
-        // stage the programs in LDS unless that costs a resident workgroup
+                     (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)8 * ps.n_init + (size_t)16 * ps.n_comp +
+                     (size_t)8 * ((a.n_fact + 1) / 2);
+        const size_t stage_bytes = sizeof(DevExpr) * ps.n_expr;
+        // stage the angle records in LDS unless that costs a resident workgroup
         const size_t budget = (size_t)160 * 1024;
         a.staged = (lds + stage_bytes <= budget && budget / (lds + stage_bytes) >= std::min<size_t>(budget / lds, 2)) ? 1 : 0;
         if (a.staged) lds += stage_bytes;
         if (rdm_dev) {
             a.red_off = (int)((lds - (((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
                                       (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
-                                      (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)16 * ((c.n_params + 1) & ~1))) / 8);
+                                      (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h))) / 8);
             lds += (size_t)8 * RDM_SLOTS * ((1 << ps.lgT) / 64);
         }
         if (lds > (size_t)160 * 1024) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: pass tables exceed LDS");
