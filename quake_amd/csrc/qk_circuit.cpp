@@ -340,6 +340,15 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         ps.lgT = ps.L >= 13 ? 9 : (ps.L >= 11 ? 8 : (ps.L == 10 ? 7 : 6));
         ps.h = ps.L <= 6 ? ps.L : 6;    // 64 columns = one wavefront; <= kMaxRowBits row bits
         ps.maxg = ps.L >= 12 ? 3 : 2;   // radix-8 sweeps need the 512-thread / 256-VGPR kernel
+        // 12 local qubits with butterflies or swaps to do: 8 waves per workgroup on the 128-register kernel (radix-4
+        // sweeps).  LDS holds two such states per CU, i.e. four waves per SIMD instead of two -- measured, 4 GiB of Psi:
+        // GA genome 3.81 -> 3.15 ms, ZZ r = 2 3.59 -> 3.45 ms, the second pass of 16-qubit ZZ r = 2 5.37 -> 5.1 ms.  A
+        // pass that is only diagonal stages (the direct store of the Z / ZZ maps) keeps 4 waves: 0.91 vs 1.19 ms.
+        {
+            bool has_nd = false;
+            for (int sid : d.stage_ids) has_nd |= !seq[sid].diag;
+            if (ps.L == 12 && has_nd) { ps.lgT = 9; ps.maxg = 2; ps.narrow = true; }
+        }
         ps.phys = d.S;
         for (int q = 0; q < n; ++q)
             if (std::find(d.S.begin(), d.S.end(), q) == d.S.end()) ps.phys.push_back(q);

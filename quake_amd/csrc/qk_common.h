@@ -104,7 +104,8 @@ struct Pass {
     int L = 0;                 // local qubits
     int lgT = 6;               // log2(threads)
     int h = 0;                 // diagonal stages: local bits < h index the low phase table, the rest the high one
-    int maxg = 2;              // largest fused single-qubit group (3 needs the 256-VGPR kernel)
+    int maxg = 2;              // largest fused single-qubit group
+    bool narrow = false;       // 512 threads on the 128-register kernel (four waves per SIMD with two workgroups per CU)
     bool first = false;        // starts from |0...0> (no load)
     // Qubits no non-diagonal gate has touched yet are still |0>: every amplitude with such a bit
     // set is exactly zero.  zero_in: those bits (virtual positions) when the pass starts -- not

@@ -358,7 +358,8 @@ __device__ __forceinline__ void scatter_angle(const DevExpr& ex, double cn, doub
     }
 }
 
-// MAXG = 3: 512 threads, up to 256 VGPRs (radix-8 sweeps); MAXG = 2: 256 threads, up to 168 VGPRs, 3 waves/SIMD
+// MAXG = 3: up to 256 VGPRs, two waves per SIMD (radix-8 sweeps, two items per trip); MAXG = 2: at most 128 VGPRs, four
+// waves per SIMD (radix-4 sweeps; without the angle interpreter, which went into angle_table_kernel, it needs 102).
 // RDM = true: the fused simulate + reduced-density-matrix variant (qk_simulate_rdm1_dev); the reduction
 // holds 16 amplitudes per thread, so it gets the 256-VGPR budget (2 waves/SIMD) of its own instantiation.
 // The workgroup's waves talk to each other through LDS only (statevectors in global memory are written by one
@@ -374,7 +375,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define QK_REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 
 template <int MAXG, bool RDM>
-__global__ void __launch_bounds__(MAXG == 3 ? 512 : 256, (MAXG == 3 || RDM) ? 2 : 3) sim_pass_kernel(SimArgs a) {
+__global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kernel(SimArgs a) {
     extern __shared__ double2 lds[];
     const int L = a.L, h = a.h;
     const uint32_t nloc = 1u << L;
@@ -1063,7 +1064,9 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.n_term = ps.n_term;
         a.L = ps.L;
         a.h = ps.h;
-        a.lgT = ps.lgT;
+        // the fused simulate + RDM mode keeps 256 threads on a pass planned for 512 (Pass::narrow): its reduction
+        // holds 16 amplitudes per thread and has the 256-register kernel to itself
+        a.lgT = (rdm_dev && ps.narrow) ? 8 : ps.lgT;
         a.n_init = ps.n_init;
         a.n_qubits = n;
         a.first = ps.first ? 1 : 0;
@@ -1099,14 +1102,14 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
             a.red_off = (int)((lds - (((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
                                       (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                                       (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h))) / 8);
-            lds += (size_t)8 * RDM_SLOTS * ((1 << ps.lgT) / 64);
+            lds += (size_t)8 * RDM_SLOTS * ((1 << a.lgT) / 64);
         }
         if (lds > (size_t)160 * 1024) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: pass tables exceed LDS");
-        const int threads = 1 << ps.lgT;
+        const int threads = 1 << a.lgT;
         // resident workgroups per CU: LDS, and registers (MAXG = 3: 2 waves/SIMD; MAXG = 2: 3 waves/SIMD)
         // a direct pass has no butterflies: the 256-thread instantiation (3 waves/SIMD) serves it whatever L is
-        const int maxg = (direct && threads <= 256) ? 2 : ps.maxg;
-        const int by_regs = ((maxg >= 3 || rdm_dev) ? 512 : 768) / threads;
+        const int maxg = ((direct && threads <= 256) || ps.narrow) ? 2 : ps.maxg;
+        const int by_regs = ((maxg >= 3 || rdm_dev) ? 512 : 1024) / threads;
         int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)by_regs);
         per_cu = std::max(1, std::min(per_cu, 16));
         const int64_t nblocks = std::min<int64_t>(a.n_items, (int64_t)256 * per_cu);
