@@ -114,6 +114,9 @@ int qk_circuit_num_passes(const qk_circuit* c);
  * reference qsvm/train.py:92,152,154, genetic_v3.py:618-619).
  *   X    : N x n_params float64, row stride ldx (elements)
  *   psi  : N x 2^n complex128, written
+ * Circuits of more than 10 qubits take a temporary table (16 bytes per sample and gate angle) from the
+ * device's default memory pool in stream order (hipMallocAsync / hipFreeAsync on `stream`): nothing outlives
+ * the call's work, no synchronisation.
  */
 int qk_simulate_dev(const qk_circuit* c, const double* X_dev, int64_t N, int64_t ldx,
                     void* psi_dev, void* stream);

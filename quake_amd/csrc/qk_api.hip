@@ -115,6 +115,19 @@ extern "C" int qk_circuit_create(int n_qubits, int n_params, const qk_op* ops, i
         delete c;
         return rc;
     }
+    bool any_narrow = false;
+    for (const Pass& ps : c->passes) any_narrow |= ps.narrow;
+    if (any_narrow) {      // the fused simulate + RDM mode runs its own plan of the same gates (see qk_circuit::rdm_plan)
+        qk_circuit* r = new (std::nothrow) qk_circuit();
+        if (!r) { delete c; return fail(QK_ERR_INVALID, "qk_circuit_create: out of memory"); }
+        r->n_qubits = n_qubits;
+        r->n_params = n_params;
+        r->prog = c->prog;
+        r->consts = c->consts;
+        const int rc2 = plan_circuit(*r, ops, n_ops, expr_off, n_expr, false);
+        if (rc2) { delete r; delete c; return rc2; }
+        c->rdm_plan = r;
+    }
     *out = c;
     return QK_OK;
 }
@@ -122,6 +135,7 @@ extern "C" int qk_circuit_create(int n_qubits, int n_params, const qk_op* ops, i
 extern "C" void qk_circuit_destroy(qk_circuit* c) {
     if (!c) return;
     free_circuit_device(*c);
+    if (c->rdm_plan) free_circuit_device(*c->rdm_plan);
     delete c;
 }
 

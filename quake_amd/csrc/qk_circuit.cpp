@@ -40,7 +40,7 @@ bool touches(const Item& t, int q) { return t.q0 == q || (t.q1 >= 0 && t.q1 == q
 
 }  // namespace
 
-int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr_off, int n_expr) {
+int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr_off, int n_expr, bool allow_narrow) {
     const int n = c.n_qubits;
     auto bad_q = [&](int q) { return q < 0 || q >= n; };
 
@@ -347,7 +347,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         {
             bool has_nd = false;
             for (int sid : d.stage_ids) has_nd |= !seq[sid].diag;
-            if (ps.L == 12 && has_nd) { ps.lgT = 9; ps.maxg = 2; ps.narrow = true; }
+            if (allow_narrow && ps.L == 12 && has_nd) { ps.lgT = 9; ps.maxg = 2; ps.narrow = true; }
         }
         ps.phys = d.S;
         for (int q = 0; q < n; ++q)

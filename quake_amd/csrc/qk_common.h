@@ -183,11 +183,15 @@ struct qk_circuit {
     // pull them away)
     std::mutex mu;
     std::map<int, qk::DevTables> tables;
+    // The same circuit planned without 512-thread passes (Pass::narrow), for the fused simulate + RDM mode, whose
+    // reduction needs the 256-register kernel (radix-8 sweeps on 256 threads); null when the two plans agree.
+    qk_circuit* rdm_plan = nullptr;
+    ~qk_circuit() { delete rdm_plan; }
 };
 
 namespace qk {
 // qk_circuit.cpp
-int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr_off, int n_expr);
+int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr_off, int n_expr, bool allow_narrow = true);
 // qk_stats.hip: noise + statistics of many small symmetric matrices in one launch (dense, ldk = N)
 struct EpiJob {
     double* K;

@@ -393,8 +393,10 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
     double* after_tables = a.hoist == 2 ? (double*)(bhi + (1u << (L - h))) : (double*)tables_end;
     DevExpr* s_expr = (DevExpr*)after_tables;              // staged DevExpr records (a.staged)
     int2* s_init = (int2*)(s_expr + (a.staged ? a.n_expr : 0));   // (virtual bit, matrix) of the hoisted first gates
-    DevComp* s_comp = (DevComp*)(s_init + a.n_init);       // composite matrices of the pass and their factor lists: read
-    int32_t* s_fact = (int32_t*)(s_comp + a.n_comp);       // per thread at the start of a sample (see const_words above)
+    // composite matrices of the pass and their factor lists, read per thread at the start of a sample: in LDS when
+    // staged (see const_words above for why), else where the host put them
+    const DevComp* s_comp = a.staged ? (const DevComp*)(s_init + a.n_init) : a.comps;
+    const int32_t* s_fact = a.staged ? (const int32_t*)((const DevComp*)(s_init + a.n_init) + a.n_comp) : a.facts;
     double* s_red = after_tables + a.red_off;              // fused-RDM partial sums
     const int tid = threadIdx.x;
     const int T = blockDim.x;
@@ -424,10 +426,11 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
         mat[4 * m + 0] = m00; mat[4 * m + 1] = m01; mat[4 * m + 2] = m10; mat[4 * m + 3] = m11;
     }
     for (int k = tid; k < a.n_init; k += T) s_init[k] = make_int2(a.stages[k].va, a.stages[k].gm[0]);
-    if (a.staged)
+    if (a.staged) {
         for (int e = tid; e < a.n_expr; e += T) s_expr[e] = a.exprs[e];
-    for (int k = tid; k < a.n_comp; k += T) s_comp[k] = a.comps[k];
-    for (int k = tid; k < a.n_fact; k += T) s_fact[k] = a.facts[k];
+        for (int k = tid; k < a.n_comp; k += T) ((DevComp*)s_comp)[k] = a.comps[k];
+        for (int k = tid; k < a.n_fact; k += T) ((int32_t*)s_fact)[k] = a.facts[k];
+    }
     // Persistent workgroups: each owns a contiguous range of (sample, chunk) items, so the launch
     // cost is paid once per CU slot and the chunks of one sample follow each other: the angle
     // programs (the longest dependent chain of an item) run once per sample, not once per chunk.
@@ -646,7 +649,20 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
             }
             lds_barrier();
             if (!fuse_init) {
-                for (uint32_t l = tid; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
+                uint32_t l = tid;
+                if (T >= (int)nlo) {     // l & (nlo - 1) is the same in every trip: one read of the column factor,
+                    const double2 fc = tlo[tid & (nlo - 1u)];
+                    for (; l + 3u * T < nloc; l += 4u * T) {     // four row factors read, then four amplitudes written
+#define QK_LD(k) const double2 r##k = thi[(l + k##u * T) >> h];
+#define QK_ST(k) state[l + k##u * T] = cmul(fc, r##k);
+                        QK_REP4(QK_LD)
+                        QK_REP4(QK_ST)
+#undef QK_LD
+#undef QK_ST
+                    }
+                    for (; l < nloc; l += T) state[l] = cmul(fc, thi[l >> h]);
+                }
+                for (; l < nloc; l += T) state[l] = cmul(tlo[l & (nlo - 1u)], thi[l >> h]);
                 lds_barrier();
             }
         }
@@ -976,7 +992,8 @@ namespace qk {
 // the workspace the earlier passes go through.
 static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx, void* psi_dev, double* rdm_dev,
                          void* stream, void* psi32_dev = nullptr) {
-    qk_circuit& c = *const_cast<qk_circuit*>(cc);
+    // rdm_dev: the plan without 512-thread passes, where the circuit has one
+    qk_circuit& c = (rdm_dev && cc->rdm_plan) ? *cc->rdm_plan : *const_cast<qk_circuit*>(cc);
     if (c.n_params > 0 && (!X_dev || ldx < c.n_params))
         return fail(QK_ERR_INVALID, "qk_simulate_dev: X is null or its row stride is smaller than the parameter count");
     DevTables dt;
@@ -987,7 +1004,15 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     // wavefront.  QK_SIM_PATH=lds keeps such circuits on the LDS kernel below (A/B runs, and the fused
     // simulate + RDM mode, which reduces from the LDS image).
     static const bool force_lds = [] { const char* e = std::getenv("QK_SIM_PATH"); return e && std::strcmp(e, "lds") == 0; }();
-    if (dt.wave && !rdm_dev && !force_lds) {
+    // A circuit that is the product state and ONE diagonal stage (the Z / ZZ / custom maps at r = 1) at 9 or 10 qubits
+    // is faster on the LDS kernel's direct-store pass now that its angles come from the pre-pass (4 GiB of Psi, 10
+    // qubits: ZZ 1.41 vs 1.89 ms, Z 1.03 vs 1.25; 9 qubits: ZZ 1.72 vs 2.54; equal at 8, the wave kernel ahead below
+    // and on everything with butterflies).  QK_SIM_PATH=wave keeps such circuits on the wave kernel.
+    static const bool force_wave = [] { const char* e = std::getenv("QK_SIM_PATH"); return e && std::strcmp(e, "wave") == 0; }();
+    const bool direct_shape = c.passes.size() == 1 && c.passes[0].n_init > 0 && c.passes[0].n_stage == c.passes[0].n_init + 1 &&
+                              c.stages[c.passes[0].stage_off + c.passes[0].n_init].kind == ST_DIAG;
+    const bool prefer_lds = n >= 9 && direct_shape && !force_wave;
+    if (dt.wave && !rdm_dev && !force_lds && !prefer_lds) {
         WaveJob job{};
         job.prog = dt.wave;
         job.X = X_dev;
@@ -1064,9 +1089,7 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.n_term = ps.n_term;
         a.L = ps.L;
         a.h = ps.h;
-        // the fused simulate + RDM mode keeps 256 threads on a pass planned for 512 (Pass::narrow): its reduction
-        // holds 16 amplitudes per thread and has the 256-register kernel to itself
-        a.lgT = (rdm_dev && ps.narrow) ? 8 : ps.lgT;
+        a.lgT = ps.lgT;
         a.n_init = ps.n_init;
         a.n_qubits = n;
         a.first = ps.first ? 1 : 0;
@@ -1091,18 +1114,20 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
                          c.stages[ps.stage_off + ps.n_stage - 1].kind == ST_DIAG) ? 1 : 0;
         size_t lds = (direct ? (size_t)0 : ((size_t)16 << ps.L)) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
                      (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
-                     (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)8 * ps.n_init + (size_t)16 * ps.n_comp +
-                     (size_t)8 * ((a.n_fact + 1) / 2);
-        const size_t stage_bytes = sizeof(DevExpr) * ps.n_expr;
-        // stage the angle records in LDS unless that costs a resident workgroup
+                     (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)8 * ps.n_init;
+        const size_t stage_bytes = sizeof(DevExpr) * ps.n_expr + (size_t)16 * ps.n_comp + (size_t)8 * ((a.n_fact + 1) / 2);
+        // stage the angle records and the composite tables in LDS unless that costs a resident workgroup
+        // (counted with everything else the workgroup holds: the fused mode's reduction scratch comes on top)
         const size_t budget = (size_t)160 * 1024;
-        a.staged = (lds + stage_bytes <= budget && budget / (lds + stage_bytes) >= std::min<size_t>(budget / lds, 2)) ? 1 : 0;
+        const size_t rdm_bytes = rdm_dev ? (size_t)8 * RDM_SLOTS * ((1 << a.lgT) / 64) : 0;
+        const size_t need0 = lds + rdm_bytes, need1 = need0 + stage_bytes;
+        a.staged = (need1 <= budget && budget / need1 >= std::min<size_t>(budget / need0, 2)) ? 1 : 0;
         if (a.staged) lds += stage_bytes;
         if (rdm_dev) {
             a.red_off = (int)((lds - (((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
                                       (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                                       (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h))) / 8);
-            lds += (size_t)8 * RDM_SLOTS * ((1 << a.lgT) / 64);
+            lds += rdm_bytes;
         }
         if (lds > (size_t)160 * 1024) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: pass tables exceed LDS");
         const int threads = 1 << a.lgT;
