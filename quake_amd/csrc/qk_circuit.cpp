@@ -344,10 +344,18 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         // sweeps).  LDS holds two such states per CU, i.e. four waves per SIMD instead of two -- measured, 4 GiB of Psi:
         // GA genome 3.81 -> 3.15 ms, ZZ r = 2 3.59 -> 3.45 ms, the second pass of 16-qubit ZZ r = 2 5.37 -> 5.1 ms.  A
         // pass that is only diagonal stages (the direct store of the Z / ZZ maps) keeps 4 waves: 0.91 vs 1.19 ms.
+        // A pass whose only non-diagonal stages are Hadamards (the layers between the diagonal stages of the Z / ZZ maps
+        // at r >= 2) keeps 256 threads on the 256-register kernel and takes them four at a time (radix 16: one item of
+        // 16 amplitudes per thread, three sweeps per layer of 12 instead of six of radix 4).
         {
-            bool has_nd = false;
-            for (int sid : d.stage_ids) has_nd |= !seq[sid].diag;
-            if (allow_narrow && ps.L == 12 && has_nd) { ps.lgT = 9; ps.maxg = 2; ps.narrow = true; }
+            bool has_nd = false, h_only = true;
+            for (int sid : d.stage_ids)
+                if (!seq[sid].diag) {
+                    has_nd = true;
+                    h_only &= seq[sid].nd.kind == ST_U1 && seq[sid].nd.gate == QK_H;
+                }
+            if (has_nd && h_only && ps.L - ps.lgT >= 4) ps.maxh = 4;
+            else if (allow_narrow && ps.L == 12 && has_nd) { ps.lgT = 9; ps.maxg = 2; ps.narrow = true; }
         }
         ps.phys = d.S;
         for (int q = 0; q < n; ++q)
@@ -471,7 +479,11 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 bool fused = false;
                 if ((int)c.stages.size() > ps.stage_off) {
                     DevStage& prev = c.stages.back();
-                    if (prev.kind == ST_U1 && prev.ng < ps.maxg && (int)c.stages.size() > ps.stage_off + ps.n_init) {
+                    bool all_h = g.gate == QK_H;
+                    if (prev.kind == ST_U1)
+                        for (int k = 0; k < prev.ng; ++k) all_h &= c.mats[ps.mat_off + prev.gm[k]].gate == QK_H;
+                    const int cap = all_h ? std::max(ps.maxg, ps.maxh) : ps.maxg;
+                    if (prev.kind == ST_U1 && prev.ng < cap && (int)c.stages.size() > ps.stage_off + ps.n_init) {
                         bool clash = false;
                         for (int k = 0; k < prev.ng; ++k) clash |= (prev.gv[k] == v);
                         if (!clash) {

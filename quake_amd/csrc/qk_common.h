@@ -45,7 +45,7 @@ struct DeviceOnce {
 
 enum StageKind : int32_t { ST_DIAG = 0, ST_U1 = 1, ST_CX = 2, ST_ECR = 3, ST_INIT = 4 };
 constexpr int kMaxRowBits = 7;  // a diagonal stage splits the local bits into h "column" and <= 7 "row" bits
-constexpr int kMaxGroup = 3;  // single-qubit gates on distinct qubits fused into one radix-8 sweep
+constexpr int kMaxGroup = 4;  // single-qubit gates on distinct qubits fused into one sweep: 3 (radix 8) in general, 4 Hadamards (radix 16)
 enum TermKind : int32_t { TM_P = 0, TM_RZ = 1, TM_CZ = 2, TM_ZZP = 3 };
 
 struct DevTerm {      // one factor of a diagonal stage (device table)
@@ -106,6 +106,7 @@ struct Pass {
     int h = 0;                 // diagonal stages: local bits < h index the low phase table, the rest the high one
     int maxg = 2;              // largest fused single-qubit group
     bool narrow = false;       // 512 threads on the 128-register kernel (four waves per SIMD with two workgroups per CU)
+    int maxh = 0;              // largest group of Hadamards in one sweep (4 = radix 16, one item per thread), 0 = as maxg
     bool first = false;        // starts from |0...0> (no load)
     // Qubits no non-diagonal gate has touched yet are still |0>: every amplitude with such a bit
     // set is exactly zero.  zero_in: those bits (virtual positions) when the pass starts -- not

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
@@ -123,20 +124,18 @@ __device__ __forceinline__ void apply_term(const RTerm& t, uint32_t w, double& f
 typedef const int32_t QK_CONST_AS* ConstWords;
 __device__ __forceinline__ ConstWords const_words(const void* p) { return (ConstWords)(uintptr_t)p; }
 
+constexpr int kStageWords = (int)(sizeof(DevStage) / sizeof(int32_t));
+constexpr int kStageXoWord = (int)(offsetof(DevStage, xo) / sizeof(int32_t));
 __device__ __forceinline__ DevStage load_stage(ConstWords stages, int idx) {
-    static_assert(sizeof(DevStage) == 24 * sizeof(int32_t), "DevStage is read word by word");
-    ConstWords w = stages + idx * 24;
+    static_assert(sizeof(DevStage) == (6 + 2 * kMaxGroup + kMaxRowBits + 1 + 4) * sizeof(int32_t), "DevStage is read word by word");
+    ConstWords w = stages + idx * kStageWords;
+    int32_t raw[kStageWords];
+#pragma unroll
+    for (int k = 0; k < kStageWords; ++k) raw[k] = w[k];
     DevStage st;
-    st.kind = w[0]; st.va = w[1]; st.vb = w[2]; st.ng = w[3];
-#pragma unroll
-    for (int k = 0; k < kMaxGroup; ++k) { st.gv[k] = w[4 + k]; st.gm[k] = w[4 + kMaxGroup + k]; }
-    st.t0 = w[10]; st.nLo = w[11]; st.nHi = w[12]; st.nX = w[13];
-#pragma unroll
-    for (int k = 0; k <= kMaxRowBits; ++k) st.xo[k] = w[14 + k];
-    st.nLoD = w[22]; st.nHiD = w[23];
+    __builtin_memcpy(&st, raw, sizeof(st));
     return st;
 }
-constexpr int kStageXoWord = 14;     // offset of DevStage::xo in words
 
 // The factor of one diagonal term as a complex number, (1, 0) where the term does not act: no branches.
 __device__ __forceinline__ double2 term_factor(const RTerm& t, uint32_t w) {
@@ -305,6 +304,69 @@ __device__ __forceinline__ void sweep_u1(double2* state, const double2* mat, Con
         for (int p = 0; p < IPT; ++p)
 #pragma unroll
             for (int k = 0; k < (1 << NG); ++k) state[b[p] | off[k]] = v[p][k];
+    }
+}
+
+// Four Hadamards on distinct local qubits in one sweep: a thread holds the 16 amplitudes that differ in the target
+// bits (one item per trip: 64 registers of amplitudes) -- three sweeps for a layer of 12 Hadamards.
+// When the targets are bits 0..3 a thread's 16 amplitudes are 256 consecutive bytes, i.e. every lane of a bank group
+// would be on the same banks in each of the 16 reads and writes.  There lane t reads amplitude k ^ s (s = t & 15) into
+// register k and writes register i to position i ^ s -- 16 lanes, 16 different slots -- and the transform is repaired
+// with signs, no data movement:  WHT(x)[i ^ s] = (-1)^(i.s + s.s) * sum_k (-1)^(i.k) [(-1)^(s.k) x[k ^ s]]   (a.b = parity
+// of a & b), i.e. flip the sign of input register k where parity(s & k), transform, flip output register i where
+// parity(s & i) ^ parity(s): XORs on the high words with per-lane masks.
+__device__ __forceinline__ void sweep_h16(double2* state, const DevStage& st, uint32_t nloc, int tid, int T) {
+    uint32_t lm[4], off[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) lm[g] = (1u << st.gv[g]) - 1u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o |= (((uint32_t)k >> g) & 1u) << st.gv[g];
+        off[k] = o;
+    }
+    const bool low = st.gv[3] == 3;     // ascending and distinct: the targets are bits 0, 1, 2, 3
+    auto flip = [](double x, uint32_t m) { return __longlong_as_double(__double_as_longlong(x) ^ (long long)((uint64_t)m << 32)); };
+    const uint32_t items = nloc >> 4;
+    for (uint32_t i = tid; i < items; i += T) {
+        uint32_t b = i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b = ((b & ~lm[g]) << 1) | (b & lm[g]);
+        const uint32_t sw = low ? (i & 15u) : 0u;
+        double2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = state[b | (off[k] ^ sw)];
+        uint32_t mask[16];
+        if (low) {
+            const uint32_t b0 = (sw & 1u) << 31, b1 = (sw & 2u) << 30, b2 = (sw & 4u) << 29, b3 = (sw & 8u) << 28;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                mask[k] = ((k & 1) ? b0 : 0u) ^ ((k & 2) ? b1 : 0u) ^ ((k & 4) ? b2 : 0u) ^ ((k & 8) ? b3 : 0u);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) v[k] = make_double2(flip(v[k].x, mask[k]), flip(v[k].y, mask[k]));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (!((k >> g) & 1)) {
+                    const int k1 = k | (1 << g);
+                    const double2 a0 = v[k], a1 = v[k1];
+                    v[k] = make_double2(a0.x + a1.x, a0.y + a1.y);
+                    v[k1] = make_double2(a0.x - a1.x, a0.y - a1.y);
+                }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = make_double2(v[k].x * 0.25, v[k].y * 0.25);
+        if (low) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t m = mask[k] ^ mask[15];
+                v[k] = make_double2(flip(v[k].x, m), flip(v[k].y, m));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) state[b | (off[k] ^ sw)] = v[k];
     }
 }
 
@@ -577,7 +639,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                         const uint32_t c = j & (nlo - 1u);
                         const uint32_t ra = __builtin_amdgcn_readfirstlane(j >> h);
                         const uint32_t w1 = c | (1u << (h + ra));
-                        ConstWords xo = c_stages + a.n_init * 24 + kStageXoWord;
+                        ConstWords xo = c_stages + a.n_init * kStageWords + kStageXoWord;
                         double gr = 1.0, gi = 0.0;
                         for (int k = xo[ra]; k < xo[ra + 1]; ++k) {
                             apply_term(tx[k], w1, fr, fi);
@@ -694,7 +756,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                         const uint32_t c = j & (nlo - 1u);
                         const uint32_t ra = __builtin_amdgcn_readfirstlane(j >> h);
                         const uint32_t w0 = whi | c, w1 = w0 | (1u << (h + ra));
-                        ConstWords xo = c_stages + s * 24 + kStageXoWord;   // from memory: indexing the register copy would spill it
+                        ConstWords xo = c_stages + s * kStageWords + kStageXoWord;   // from memory: indexing the register copy would spill it
                         double gr = 1.0, gi = 0.0;
                         for (int k = xo[ra]; k < xo[ra + 1]; ++k) {
                             apply_term(tx[k], w1, fr, fi);
@@ -795,7 +857,10 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
             } else if (st.kind == ST_U1) {
                 if (st.ng == 1) sweep_u1_any<1>(state, mat, c_mats, st, nloc, tid, T);
                 else if (st.ng == 2) sweep_u1_any<2>(state, mat, c_mats, st, nloc, tid, T);
-                else if constexpr (MAXG >= 3) sweep_u1_any<3>(state, mat, c_mats, st, nloc, tid, T);
+                else if constexpr (MAXG >= 3) {
+                    if (st.ng == 3) sweep_u1_any<3>(state, mat, c_mats, st, nloc, tid, T);
+                    else sweep_h16(state, st, nloc, tid, T);      // four Hadamards (the planner groups nothing else by four)
+                }
             } else if (st.kind == ST_CX) {
                 const int vc = st.va, vt = st.vb;
                 if (vc >= L) {  // control is a chunk bit: X on the target, or nothing
