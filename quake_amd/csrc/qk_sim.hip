@@ -38,6 +38,10 @@ struct SimArgs {
     const DevComp* comps;    // composite matrices of the pass and their factor lists (pass-local matrix indices)
     const int32_t* facts;
     int n_comp, n_fact;
+    // every qubit's first gate is a Hadamard (each hand-written map): the product state is the constant 2^(-n/2), its
+    // factors over the low / high local bits and the chunk bits are these three numbers instead of n table look-ups
+    int init_h;
+    double init_lo, init_hi, init_chunk;
     int n_stage, n_expr, n_mat, n_term;
     int staged;                                // the pass's DevExpr records (destinations of the angles) are copied to LDS
     int red_off;                               // fused-RDM scratch: offset in doubles from the end of the phase tables
@@ -60,8 +64,10 @@ struct SimArgs {
 // thread 0 of every workgroup adds up the 100 MHz ticks between the marks below and leaves the sums in a table.
 #ifdef QK_SIM_TRACE
 #define QK_MARK(k) do { if (tid == 0) { const uint64_t t_ = wall_clock64(); tr_acc[k] += (double)(t_ - tr_last); tr_last = t_; } } while (0)
+#define QK_MARK2(k) do { if (tid == 0) { const uint64_t t_ = wall_clock64(); tr_acc2[k] += (double)(t_ - tr_last); tr_last = t_; } } while (0)
 #else
 #define QK_MARK(k) do { } while (0)
+#define QK_MARK2(k) do { } while (0)
 #endif
 
 // a diagonal term with its per-sample (cos, sin) resolved, 32 bytes in LDS
@@ -129,11 +135,16 @@ constexpr int kStageXoWord = (int)(offsetof(DevStage, xo) / sizeof(int32_t));
 __device__ __forceinline__ DevStage load_stage(ConstWords stages, int idx) {
     static_assert(sizeof(DevStage) == (6 + 2 * kMaxGroup + kMaxRowBits + 1 + 4) * sizeof(int32_t), "DevStage is read word by word");
     ConstWords w = stages + idx * kStageWords;
-    int32_t raw[kStageWords];
+    constexpr int G = kMaxGroup, X = kStageXoWord;
+    static_assert(X == 8 + 2 * G && offsetof(DevStage, t0) == (4 + 2 * G) * sizeof(int32_t), "field offsets below");
+    DevStage st;      // (xo[] is read from memory where it is needed: indexing this copy puts the whole record in scratch)
+    st.kind = w[0]; st.va = w[1]; st.vb = w[2]; st.ng = w[3];
 #pragma unroll
-    for (int k = 0; k < kStageWords; ++k) raw[k] = w[k];
-    DevStage st;
-    __builtin_memcpy(&st, raw, sizeof(st));
+    for (int k = 0; k < G; ++k) { st.gv[k] = w[4 + k]; st.gm[k] = w[4 + G + k]; }
+    st.t0 = w[4 + 2 * G]; st.nLo = w[5 + 2 * G]; st.nHi = w[6 + 2 * G]; st.nX = w[7 + 2 * G];
+#pragma unroll
+    for (int k = 0; k <= kMaxRowBits; ++k) st.xo[k] = w[X + k];
+    st.nLoD = w[X + kMaxRowBits + 1]; st.nHiD = w[X + kMaxRowBits + 2];
     return st;
 }
 
@@ -527,6 +538,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
     int64_t angles_of = -1;     // the sample whose (cos, sin) values sit in rt / mat
     const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef QK_SIM_TRACE
+    double tr_acc2[4] = {0, 0, 0, 0};   // finer split of the diagonal stage's table phase: 0 stage record, 1 tables, 2 barrier
     double tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 load + angles + tables, 1 product state, 2 diag tables, 3 diag sweep, 4 u1, 5 cx / ecr, 6 store, 7 items
     uint64_t tr_last = wall_clock64();
     const uint64_t tr_begin = tr_last;
@@ -628,7 +640,8 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                 const bool all = a.hoist == 1;
                 const int n_tl = all ? st.nLo : st.nLo - st.nLoD, n_th = all ? st.nHi : st.nHi - st.nHiD;
                 double2 gs = make_double2((all && (whi & a.zero_in)) ? 0.0 : 1.0, 0.0);
-                if (all)
+                if (all && a.init_h) gs.x = a.init_chunk;
+                else if (all)
                     for (int q = 0; q < a.n_init; ++q) {
                         const int2 g = s_init[q];
                         if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
@@ -639,9 +652,8 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                         const uint32_t c = j & (nlo - 1u);
                         const uint32_t ra = __builtin_amdgcn_readfirstlane(j >> h);
                         const uint32_t w1 = c | (1u << (h + ra));
-                        ConstWords xo = c_stages + a.n_init * kStageWords + kStageXoWord;
                         double gr = 1.0, gi = 0.0;
-                        for (int k = xo[ra]; k < xo[ra + 1]; ++k) {
+                        for (int k = (c_stages + a.n_init * kStageWords + kStageXoWord)[ra], k1 = (c_stages + a.n_init * kStageWords + kStageXoWord)[ra + 1]; k < k1; ++k) {
                             apply_term(tx[k], w1, fr, fi);
                             apply_term(tx[k], c, gr, gi);
                         }
@@ -652,7 +664,8 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                         const uint32_t wl = is_lo ? e : (e << h);
                         const uint32_t w = all ? (whi | wl) : wl;
                         double2 f = (wl & a.zero_in) ? make_double2(0.0, 0.0) : (is_lo ? gs : make_double2(1.0, 0.0));
-                        f = init_factors(s_init, a.n_init, mat, L, h, is_lo, w, f);
+                        if (a.init_h) { const double sc = is_lo ? a.init_lo : a.init_hi; f = make_double2(f.x * sc, f.y * sc); }
+                        else f = init_factors(s_init, a.n_init, mat, L, h, is_lo, w, f);
                         fr = f.x; fi = f.y;
                         if (is_lo) {
                             apply_terms(tl, n_tl, w, fr, fi);
@@ -678,10 +691,12 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
             const RTerm* thd = rt + st.t0 + st.nLo + (st.nHi - st.nHiD);
             const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
             double2 gs = make_double2((whi & a.zero_in) ? 0.0 : 1.0, 0.0);
-            for (int s = 0; s < a.n_init; ++s) {
-                const int2 g = s_init[s];
-                if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
-            }
+            if (a.init_h) gs.x = a.init_chunk;
+            else
+                for (int s = 0; s < a.n_init; ++s) {
+                    const int2 g = s_init[s];
+                    if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
+                }
             for (uint32_t j = tid; j < nlo + nhi; j += T) {
                 const bool is_lo = j < nlo;
                 double2 f = is_lo ? cmul(blo[j], gs) : bhi[j - nlo];
@@ -698,15 +713,18 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
         } else if (a.first && !hoist) {
             const uint32_t nlo = 1u << h, nhi = 1u << (L - h);
             double2 gs = make_double2((whi & a.zero_in) ? 0.0 : 1.0, 0.0);
-            for (int s = 0; s < a.n_init; ++s) {
-                const int2 g = s_init[s];
-                if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
-            }
+            if (a.init_h) gs.x = a.init_chunk;
+            else
+                for (int s = 0; s < a.n_init; ++s) {
+                    const int2 g = s_init[s];
+                    if (g.x >= L) gs = cmul(gs, mat[4 * g.y + 2 * ((whi >> g.x) & 1u)]);
+                }
             for (uint32_t j = tid; j < nlo + nhi; j += T) {
                 const bool is_lo = j < nlo;
                 const uint32_t w = is_lo ? j : ((j - nlo) << h);
                 double2 f = (w & a.zero_in) ? make_double2(0.0, 0.0) : (is_lo ? gs : make_double2(1.0, 0.0));
-                f = init_factors(s_init, a.n_init, mat, L, h, is_lo, w, f);
+                if (a.init_h) { const double sc = is_lo ? a.init_lo : a.init_hi; f = make_double2(f.x * sc, f.y * sc); }
+                else f = init_factors(s_init, a.n_init, mat, L, h, is_lo, w, f);
                 (is_lo ? tlo[j] : thi[j - nlo]) = f;
             }
             lds_barrier();
@@ -750,15 +768,15 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                 const bool to_hbm = a.direct || (a.last_direct && s == a.n_stage - 1);   // this sweep produces the final amplitudes
                 // work items: the ratio table first (64 columns: a wavefront shares its row bit, so
                 // the term ranges are scalar reads), then the column and the row tables
+                QK_MARK2(0);
                 if (!(fused && hoist)) for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
                     double fr = 1.0, fi = 0.0;
                     if (j < n_rat) {
                         const uint32_t c = j & (nlo - 1u);
                         const uint32_t ra = __builtin_amdgcn_readfirstlane(j >> h);
                         const uint32_t w0 = whi | c, w1 = w0 | (1u << (h + ra));
-                        ConstWords xo = c_stages + s * kStageWords + kStageXoWord;   // from memory: indexing the register copy would spill it
                         double gr = 1.0, gi = 0.0;
-                        for (int k = xo[ra]; k < xo[ra + 1]; ++k) {
+                        for (int k = (c_stages + s * kStageWords + kStageXoWord)[ra], k1 = (c_stages + s * kStageWords + kStageXoWord)[ra + 1]; k < k1; ++k) {
                             apply_term(tx[k], w1, fr, fi);
                             apply_term(tx[k], w0, gr, gi);
                         }
@@ -775,8 +793,9 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                         thi[r] = fused ? cmul(thi[r], make_double2(fr, fi)) : make_double2(fr, fi);
                     }
                 }
+                QK_MARK2(1);
                 lds_barrier();
-                QK_MARK(2);
+                QK_MARK2(2);
                 if (st.nX == 0) {
                     if (fused && to_hbm) {
                         for (uint32_t l = tid; l < nloc; l += T) store_direct(l, cmul(tlo[l & (nlo - 1u)], thi[l >> h]));
@@ -982,7 +1001,8 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
         a.trace[(int64_t)blockIdx.x * 16 + 8] = (double)tr_angles;                    // part of slot 0: up to the end of thread 0's angle program
         a.trace[(int64_t)blockIdx.x * 16 + 9] = (double)(wall_clock64() - tr_begin);  // the workgroup's whole item loop
         a.trace[(int64_t)blockIdx.x * 16 + 10] = (double)tr_begin;
-        a.trace[(int64_t)blockIdx.x * 16 + 11] = (double)tr_pre;                      // part of slot 0: up to the start of the angle programs
+        a.trace[(int64_t)blockIdx.x * 16 + 11] = (double)tr_pre;
+        for (int k = 0; k < 4; ++k) a.trace[(int64_t)blockIdx.x * 16 + 12 + k] = tr_acc2[k];                      // part of slot 0: up to the start of the angle programs
     }
 #endif
 }
@@ -1147,6 +1167,16 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.comps = dt.comps + ps.comp_off;
         a.facts = dt.facts + ps.fact_off;
         a.n_comp = ps.n_comp;
+        {
+            bool all_h = ps.first && ps.n_init == n;
+            for (int k = 0; all_h && k < ps.n_init; ++k) all_h = c.mats[ps.mat_off + c.stages[ps.stage_off + k].gm[0]].gate == QK_H;
+            a.init_h = all_h ? 1 : 0;
+            const double r = 0.70710678118654752440;
+            auto rpow = [&](int k) { return std::ldexp((k & 1) ? r : 1.0, -(k / 2)); };     // 2^(-k/2)
+            a.init_lo = rpow(ps.h);
+            a.init_hi = rpow(ps.L - ps.h);
+            a.init_chunk = rpow(n - ps.L);
+        }
         a.n_fact = (int)((pi + 1 < c.passes.size() ? c.passes[pi + 1].fact_off : (int)c.facts.size()) - ps.fact_off);
         a.n_stage = ps.n_stage;
         a.n_expr = ps.n_expr;

@@ -52,5 +52,6 @@ for n in a.qubits:
                           "us_per_item_total": round(float(per_item_us.sum()), 3),
                           "of_slot0_until_angle_programs_start_us": round(float(t[:, 11].sum() / items / 100.0), 3),
                           "of_slot0_until_own_angle_done_us": round(float(t[:, 8].sum() / items / 100.0), 3),
+                          "diag_tables_split_us(stage record, tables, barrier)": [round(float(x), 3) for x in t[:, 12:15].sum(0) / items / 100.0],
                           "workgroup_loop_us_med": round(float(np.median(t[:, 9]) / 100.0), 1),
                           "workgroup_start_spread_us": round(float((t[:, 10].max() - t[:, 10].min()) / 100.0), 1)}), flush=True)
