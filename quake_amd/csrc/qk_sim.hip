@@ -42,6 +42,7 @@ struct SimArgs {
     // factors over the low / high local bits and the chunk bits are these three numbers instead of n table look-ups
     int init_h;
     double init_lo, init_hi, init_chunk;
+    int dep_bytes;               // size of the deposit tables in LDS (a multiple of 16)
     int n_stage, n_expr, n_mat, n_term;
     int staged;                                // the pass's DevExpr records (destinations of the angles) are copied to LDS
     int red_off;                               // fused-RDM scratch: offset in doubles from the end of the phase tables
@@ -463,7 +464,12 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
     // sample): it IS tlo / thi
     double2* blo = a.hoist == 2 ? tables_end : tlo;
     double2* bhi = a.hoist == 2 ? blo + (1u << h) : thi;
-    double* after_tables = a.hoist == 2 ? (double*)(bhi + (1u << (L - h))) : (double*)tables_end;
+    // deposit(l) for every local index, as two tables (the map is linear over disjoint bits): dep_lo[l & (2^h - 1)] |
+    // dep_hi[l >> h].  Evaluated per amplitude, deposit() is a loop over the pass's bit runs whose masks and shifts come
+    // from kernel-argument memory by scalar loads -- a chain of scalar-load latencies per stored amplitude.
+    uint32_t* dep_lo = (uint32_t*)(a.hoist == 2 ? (bhi + (1u << (L - h))) : tables_end);
+    uint32_t* dep_hi = dep_lo + (1u << h);
+    double* after_tables = (double*)((char*)dep_lo + a.dep_bytes);
     DevExpr* s_expr = (DevExpr*)after_tables;              // staged DevExpr records (a.staged)
     int2* s_init = (int2*)(s_expr + (a.staged ? a.n_expr : 0));   // (virtual bit, matrix) of the hoisted first gates
     // composite matrices of the pass and their factor lists, read per thread at the start of a sample: in LDS when
@@ -499,6 +505,8 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
         mat[4 * m + 0] = m00; mat[4 * m + 1] = m01; mat[4 * m + 2] = m10; mat[4 * m + 3] = m11;
     }
     for (int k = tid; k < a.n_init; k += T) s_init[k] = make_int2(a.stages[k].va, a.stages[k].gm[0]);
+    for (uint32_t k = tid; k < (1u << h) + (1u << (L - h)); k += T)
+        dep_lo[k] = k < (1u << h) ? deposit(k, a) : deposit((k - (1u << h)) << h, a);
     if (a.staged) {
         for (int e = tid; e < a.n_expr; e += T) s_expr[e] = a.exprs[e];
         for (int k = tid; k < a.n_comp; k += T) ((DevComp*)s_comp)[k] = a.comps[k];
@@ -576,9 +584,10 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
         // ---- chunk load -----------------------------------------------------------------
         // amplitudes with a bit of a still-|0> qubit set are zero by construction: never loaded
         const uint32_t chunk_phys = deposit(whi, a);
+        auto dep_local = [&](uint32_t l) { return dep_lo[l & ((1u << h) - 1u)] | dep_hi[l >> h]; };
         double2* gpsi = a.psi + sample * a.D;
         auto store_direct = [&](uint32_t l, double2 v) {     // direct mode: the one place an amplitude is written
-            const int64_t at = chunk_phys | deposit(l, a);
+            const int64_t at = chunk_phys | dep_local(l);
             if (a.psi32) (a.psi32 + sample * a.D)[at] = make_float2((float)v.x, (float)v.y);
             else gpsi[at] = v;
         };
@@ -591,7 +600,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                 uint32_t l = tid;
                 for (; l + 7u * T < nloc; l += 8u * T) {
 #define QK_LD(k) const uint32_t l##k = l + k##u * T; \
-                 const double2 v##k = (l##k & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | deposit(l##k, a)];
+                 const double2 v##k = (l##k & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | dep_local(l##k)];
 #define QK_ST(k) state[l##k] = v##k;
                     QK_REP8(QK_LD)
                     QK_REP8(QK_ST)
@@ -599,7 +608,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
 #undef QK_ST
                 }
                 for (; l < nloc; l += T)
-                    state[l] = (l & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | deposit(l, a)];
+                    state[l] = (l & a.zero_in) ? make_double2(0.0, 0.0) : gpsi[chunk_phys | dep_local(l)];
             }
         }
         // ---- per-sample gate angles -> (cos, sin) into their term or matrix ---------------
@@ -829,7 +838,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                         // LDS and FP64 latencies nothing hides.  (The fused form below, which reads no amplitudes, keeps the walk:
                         // measured, 4.9 vs 6.0 us per 12-qubit item.)
                         const double2 rr01 = cmul(rr0, rr1);
-                        const uint32_t dep_c = to_hbm ? deposit(c, a) : 0u;
+                        const uint32_t dep_c = to_hbm ? dep_lo[c] : 0u;
                         for (uint32_t i0 = 0; i0 < rpw; i0 += 4) {
                             const uint32_t r = r0 | i0;
                             const double2 t0 = thi[r], t1 = thi[r + 1], t2 = thi[r + 2], t3 = thi[r + 3];
@@ -844,7 +853,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                             if (to_hbm) {
                                 // deposit() is linear over disjoint bits: the column's part once per item, the row's part
                                 // wave-uniform
-#define QK_ST(j) { const int64_t at = chunk_phys | dep_c | deposit((r + j##u) << h, a); \
+#define QK_ST(j) { const int64_t at = chunk_phys | dep_c | dep_hi[r + j##u]; \
                    if (a.psi32) (a.psi32 + sample * a.D)[at] = make_float2((float)f##j.x, (float)f##j.y); \
                    else gpsi[at] = f##j; }
                                 QK_REP4(QK_ST)
@@ -972,20 +981,20 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
             float2* g32 = a.psi32 + sample * a.D;
             for (uint32_t l = tid; l < nloc; l += T) {
                 const double2 v = state[l];
-                g32[chunk_phys | deposit(l, a)] = make_float2((float)v.x, (float)v.y);
+                g32[chunk_phys | dep_local(l)] = make_float2((float)v.x, (float)v.y);
             }
         } else if (!RDM || a.psi) {
             uint32_t l = tid;
             for (; l + 7u * T < nloc; l += 8u * T) {
 #define QK_LD(k) const double2 v##k = state[l + k##u * T];
-#define QK_ST(k) if (!((l + k##u * T) & a.zero_out)) gpsi[chunk_phys | deposit(l + k##u * T, a)] = v##k;
+#define QK_ST(k) if (!((l + k##u * T) & a.zero_out)) gpsi[chunk_phys | dep_local(l + k##u * T)] = v##k;
                 QK_REP8(QK_LD)
                 QK_REP8(QK_ST)
 #undef QK_LD
 #undef QK_ST
             }
             for (; l < nloc; l += T)
-                if (!(l & a.zero_out)) gpsi[chunk_phys | deposit(l, a)] = state[l];
+                if (!(l & a.zero_out)) gpsi[chunk_phys | dep_local(l)] = state[l];
         }
         // LDS is reused by the next item.  A bare barrier: every wave's LDS reads have returned
         // before it issued its stores, and the stores themselves need not have landed.
@@ -1207,7 +1216,8 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.direct = direct ? 1 : 0;
         a.last_direct = (!direct && !rdm_dev && ps.zero_out == 0 && pi + 1 == c.passes.size() && ps.n_stage > 0 &&
                          c.stages[ps.stage_off + ps.n_stage - 1].kind == ST_DIAG) ? 1 : 0;
-        size_t lds = (direct ? (size_t)0 : ((size_t)16 << ps.L)) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
+        a.dep_bytes = (int)((4 * ((1u << ps.h) + (1u << (ps.L - ps.h))) + 15u) & ~15u);
+        size_t lds = (direct ? (size_t)0 : ((size_t)16 << ps.L)) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat + (size_t)a.dep_bytes +
                      (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                      (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h) + (size_t)8 * ps.n_init;
         const size_t stage_bytes = sizeof(DevExpr) * ps.n_expr + (size_t)16 * ps.n_comp + (size_t)8 * ((a.n_fact + 1) / 2);
@@ -1219,7 +1229,7 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.staged = (need1 <= budget && budget / need1 >= std::min<size_t>(budget / need0, 2)) ? 1 : 0;
         if (a.staged) lds += stage_bytes;
         if (rdm_dev) {
-            a.red_off = (int)((lds - (((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat +
+            a.red_off = (int)((lds - (((size_t)16 << ps.L) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat + (size_t)a.dep_bytes +
                                       (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
                                       (size_t)16 * ((size_t)(ps.L - ps.h) << ps.h))) / 8);
             lds += rdm_bytes;
