@@ -1248,6 +1248,10 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         const int by_regs = ((maxg >= 3 || rdm_dev) ? 512 : 1024) / threads;
         int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)by_regs);
         per_cu = std::max(1, std::min(per_cu, 16));
+        // one-wave workgroups with sweeps to do: past 12 (8 qubits) or 8 (9 qubits) of them a CU gets slower, not faster
+        // (ZZ r = 2, 2 GiB: 8 qubits 3.33 ms at 12 against 3.98 at 16; 9 qubits 2.84 at 8 against 3.59 at 12); a pass that
+        // only stores keeps all it can get
+        if (!direct && threads == 64) per_cu = std::min(per_cu, ps.L >= 9 ? 8 : 12);
         const int64_t nblocks = std::min<int64_t>(a.n_items, (int64_t)256 * per_cu);
         const dim3 grid((unsigned)nblocks), block(threads);
         if (rdm_dev && maxg >= 3) hipLaunchKernelGGL((sim_pass_kernel<3, true>), grid, block, lds, (hipStream_t)stream, a);
