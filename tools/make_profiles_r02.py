@@ -73,7 +73,8 @@ WRITE_SIZE {sB['WRITE_SIZE']*1024:.4g} B (= N * 2^16 * 16 B, the algorithmic byt
 
 ## simulator kernels: `tools/sim_bench.py --qubits q --gib 1 --maps zz_r1 zz_r2` (per dispatch, launch order: 4x zz_r1, then zz_r2)
 
-8 and 10 qubits run on the wave-resident kernel (qk::wave_sim_kernel<NREG>), 12 and 16 on the LDS kernel (qk::sim_pass_kernel).
+zz_r2 at 8 and 10 qubits runs on the wave-resident kernel (qk::wave_sim_kernel<NREG>); zz_r1 at 8 and 10 qubits and everything at 12 and 16 on the LDS kernel
+(qk::sim_pass_kernel; its gate angles come from qk::angle_table_kernel, a separate dispatch not listed here).
 Per SAMPLE figures = counter / samples of the dispatch (wave-instructions, not lane-instructions).
 
 | qubits | kernel | dispatch | ms | samples | SQ_INSTS_VALU /sample | SQ_INSTS_SALU /sample | SQ_INSTS_LDS /sample | VALU lane-instr / amplitude | ACTIVE / WAIT_ANY / WAIT_INST of wave cycles |
@@ -136,7 +137,7 @@ for tag, f in (("wave / default", "sim_bench.json"), ("lds forced", "sim_bench_l
             r = json.loads(line)
             rows.setdefault((r["n"], r["map"]), {})[tag] = r
 sb = "# r02 simulator bench: `tools/sim_bench.py --gib 4` (4 GiB of Psi per launch; algorithmic bytes = 16 * 2^n per sample)\n\n"
-sb += "Default path: wave-resident kernel up to 10 qubits, LDS kernel above.  `QK_SIM_PATH=lds` forces the LDS kernel (round-1 path) at 8 and 10 qubits.\n\n"
+sb += "Default path: wave-resident kernel up to 10 qubits -- except circuits that are the product state and one diagonal stage (zz_r1 here), which go to the LDS kernel's direct-store pass from 6 (Z / ZZ) or 9 qubits -- and the LDS kernel above.  `QK_SIM_PATH=lds` forces the LDS kernel at 8 and 10 qubits (last two columns: its time, and its time / the default path's).\n\n"
 sb += "| qubits | circuit | samples | default ms | default GB/s | frac of 8 TB/s | LDS-kernel ms | speed-up |\n|---|---|---|---|---|---|---|---|\n"
 for (n, m), v in sorted(rows.items(), key=lambda kv: (-kv[0][0], kv[0][1])):
     d = v.get("wave / default")
