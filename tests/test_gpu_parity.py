@@ -55,6 +55,22 @@ def test_statevectors_large_and_multipass(n, builder, repeats, N):
     assert np.abs(got - O.statevectors(oops, n, X)).max() < TOL_PSI
 
 
+@pytest.mark.parametrize("n,builder,repeats,N", [
+    (11, "zz", 2, 5), (11, "z", 3, 3), (12, "zz", 2, 5), (12, "z", 3, 3), (12, "zz_full", 2, 3), (13, "zz", 2, 3), (13, "z", 3, 2),
+    (12, "custom1", 2, 3), (13, "custom2", 2, 2),
+])
+def test_statevectors_hadamard_layers(n, builder, repeats, N):
+    """Layers of Hadamards between diagonal stages in ONE pass (11, 12 and 13 local qubits: 128, 256 and 512 threads):
+    the simulator takes them four to a sweep (radix 16), the sweep over qubits 0-3 through lane-rotated positions with
+    sign repair; the custom maps mix other gates in and keep the general sweeps."""
+    X = synth_X(N, n, "scaled", 300 + n)
+    circ, oops, _ = map_pairs(n, repeats)[builder]
+    k = HipFidelityKernel(circ)
+    got = k.statevectors(X)
+    assert k._circuit().num_passes == 1
+    assert np.abs(got - O.statevectors(oops, n, X)).max() < TOL_PSI
+
+
 def _fresh_qubit_circuit(n):
     """First gates on high (non-local) qubits in every flavour the planner distinguishes."""
     x = qc.ParameterVector("x", 4)
