@@ -355,6 +355,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                     h_only &= seq[sid].nd.kind == ST_U1 && seq[sid].nd.gate == QK_H;
                 }
             if (has_nd && h_only && ps.L == 11) { ps.lgT = 7; ps.maxg = 3; }     // 16 amplitudes per thread here too
+            if (has_nd && h_only && ps.L == 10) { ps.lgT = 6; ps.maxg = 3; }
             if (has_nd && h_only && ps.L - ps.lgT >= 4) ps.maxh = 4;
             else if (allow_narrow && ps.L == 12 && has_nd) { ps.lgT = 9; ps.maxg = 2; ps.narrow = true; }
         }

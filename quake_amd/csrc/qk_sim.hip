@@ -1113,7 +1113,24 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         for (int k = 0; all_h && k < ps.n_init; ++k) all_h = c.mats[ps.mat_off + c.stages[ps.stage_off + k].gm[0]].gate == QK_H;
         return all_h;
     };
-    const bool prefer_lds = direct_shape && !force_wave && (n >= 9 || (n >= 6 && all_h_init(c.passes[0])));
+    // ... and at 10 qubits the maps at r >= 2 as well (diagonal stages and layers of Hadamards only: radix-16 sweeps,
+    // 16 amplitudes per lane of a one-wave workgroup): ZZ r = 2 3.74 vs 4.40 ms; level at 9 qubits, behind at 8.
+    auto h_layers_shape = [&]() {
+        if (c.passes.size() != 1) return false;
+        const Pass& ps = c.passes[0];
+        bool layers = false;
+        for (int k = ps.n_init; k < ps.n_stage; ++k) {
+            const DevStage& st = c.stages[ps.stage_off + k];
+            if (st.kind == ST_DIAG) continue;
+            if (st.kind != ST_U1) return false;
+            for (int g = 0; g < st.ng; ++g)
+                if (c.mats[ps.mat_off + st.gm[g]].gate != QK_H) return false;
+            layers = true;
+        }
+        return layers;
+    };
+    const bool prefer_lds = !force_wave && ((direct_shape && (n >= 9 || (n >= 6 && all_h_init(c.passes[0])))) ||
+                                            (n == 10 && h_layers_shape()));
     if (dt.wave && !rdm_dev && !force_lds && !prefer_lds) {
         WaveJob job{};
         job.prog = dt.wave;
