@@ -206,7 +206,7 @@ class CircuitHandle:
         lib = load()
         lib.qk_circuit_plan_summary.restype = C.c_int
         lib.qk_circuit_plan_summary.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
-        buf = C.create_string_buffer(512)
+        buf = C.create_string_buffer(2048)
         check(lib.qk_circuit_plan_summary(self._h, buf, len(buf)))
         return buf.value.decode()
 

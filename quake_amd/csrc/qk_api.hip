@@ -146,7 +146,23 @@ extern "C" int qk_circuit_num_passes(const qk_circuit* c) { return c ? (int)c->p
 // Development hook (not in the public header): what the planner made of the gate list, as text.
 extern "C" int qk_circuit_plan_summary(const qk_circuit* c, char* buf, int len) {
     if (!c || !buf || len < 1) return QK_ERR_INVALID;
-    std::snprintf(buf, (size_t)len, "%s; passes %d", c->plan_summary.c_str(), (int)c->passes.size());
+    std::string s = c->plan_summary + "; passes " + std::to_string(c->passes.size());
+    for (size_t pi = 0; pi < c->passes.size(); ++pi) {     // per pass: local qubits, threads, sweep radices, stage counts
+        const Pass& ps = c->passes[pi];
+        int n_u1 = 0, n_diag = 0, n_other = 0, max_ng = 0;
+        for (int k = ps.n_init; k < ps.n_stage; ++k) {
+            const DevStage& st = c->stages[ps.stage_off + k];
+            if (st.kind == ST_U1) { ++n_u1; max_ng = std::max(max_ng, (int)st.ng); }
+            else if (st.kind == ST_DIAG) ++n_diag;
+            else ++n_other;
+        }
+        s += "; pass" + std::to_string(pi) + " L" + std::to_string(ps.L) + " T" + std::to_string(1 << ps.lgT) + " maxg" +
+             std::to_string(ps.maxg) + " maxh" + std::to_string(ps.maxh) + " narrow" + std::to_string(ps.narrow ? 1 : 0) + " u1=" +
+             std::to_string(n_u1) + "(<=" + std::to_string(max_ng) + ") diag=" + std::to_string(n_diag) + " other=" +
+             std::to_string(n_other);
+    }
+    s += c->rdm_plan ? "; rdm_plan yes" : "; rdm_plan no";
+    std::snprintf(buf, (size_t)len, "%s", s.c_str());
     return QK_OK;
 }
 
