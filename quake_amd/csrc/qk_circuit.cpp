@@ -426,6 +426,26 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             ps.n_init = (int)inits.size();
         }
         ps.zero_in = mask_of(~active & ((n >= 32) ? 0xffffffffu : ((1u << n) - 1u)));
+        std::vector<int32_t> prev_diag_sig;
+        int prev_diag_stage = -1;
+        // angle programs by content: every gate carries its own program, the layers of a map repeat the same ones
+        auto same_expr = [&](int x, int y) {
+            const int lx = expr_off[x + 1] - expr_off[x], ly = expr_off[y + 1] - expr_off[y];
+            if (lx != ly) return false;
+            for (int k = 0; k < lx; ++k) {
+                const qk_instr& p = c.prog[expr_off[x] + k];
+                const qk_instr& q = c.prog[expr_off[y] + k];
+                if (p.op != q.op) return false;
+                if (p.op == QK_EX_CONST ? c.consts[p.arg] != c.consts[q.arg] : (p.op == QK_EX_PARAM && p.arg != q.arg)) return false;
+            }
+            return true;
+        };
+        auto canon_expr = [&](int e) {
+            if (e < 0) return e;
+            for (int y = 0; y < e; ++y)
+                if (same_expr(e, y)) return y;
+            return e;
+        };
         for (int s : d.stage_ids) {
             const Proto& p = seq[s];
             DevStage st{};
@@ -463,12 +483,21 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                     while (k < st.nX && row_bit(cross[k].first) < a) ++k;
                     st.xo[a] = k;
                 }
-                for (auto* grp : {&lo, &hi, &cross})
+                std::vector<int32_t> sig;      // what the stage's phase tables depend on, in table order
+                for (auto* grp : {&lo, &hi, &cross}) {
+                    sig.push_back(-1);
                     for (auto& te : *grp) {
                         c.terms.push_back(te.first);
                         if (te.second >= 0)
                             add_expr(te.second, te.first.type == TM_RZ ? 0.5 : 1.0, (int)c.terms.size() - 1 - ps.term_off);
+                        sig.insert(sig.end(), {te.first.type, te.first.va, te.first.vb, canon_expr(te.second)});
                     }
+                }
+                // the layers of a map at r >= 2 repeat the same diagonal stage: its tables are built once
+                if (!prev_diag_sig.empty() && sig == prev_diag_sig)
+                    st.reuse = (prev_diag_stage == ps.stage_off + ps.n_init && ps.first) ? 2 : 1;
+                prev_diag_sig = sig;
+                prev_diag_stage = (int)c.stages.size();
                 c.stages.push_back(st);
                 continue;
             }

@@ -68,6 +68,10 @@ struct DevStage {
     // the last nLoD of the nLo and the last nHiD of the nHi involve a chunk bit (>= L): only those have
     // to be re-evaluated from one chunk of a sample to the next
     int32_t nLoD, nHiD;
+    // DIAG: the stage has exactly the terms (kinds, bits, angles) of the diagonal stage before it in the pass, whose
+    // phase tables are still in LDS: 1 = use them as they are, 2 = that stage was the one fused with the product
+    // state (its tables carry the product state's factors: usable when those are constants, see SimArgs::init_h)
+    int32_t reuse;
     // INIT: the first gate on a still-|0> qubit (virtual bit va, local or chunk):
     //       amplitude *= entry [bit va][0] of matrix gm[0]
 };

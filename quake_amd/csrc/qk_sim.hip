@@ -134,7 +134,7 @@ __device__ __forceinline__ ConstWords const_words(const void* p) { return (Const
 constexpr int kStageWords = (int)(sizeof(DevStage) / sizeof(int32_t));
 constexpr int kStageXoWord = (int)(offsetof(DevStage, xo) / sizeof(int32_t));
 __device__ __forceinline__ DevStage load_stage(ConstWords stages, int idx) {
-    static_assert(sizeof(DevStage) == (6 + 2 * kMaxGroup + kMaxRowBits + 1 + 4) * sizeof(int32_t), "DevStage is read word by word");
+    static_assert(sizeof(DevStage) == (6 + 2 * kMaxGroup + kMaxRowBits + 1 + 5) * sizeof(int32_t), "DevStage is read word by word");
     ConstWords w = stages + idx * kStageWords;
     constexpr int G = kMaxGroup, X = kStageXoWord;
     static_assert(X == 8 + 2 * G && offsetof(DevStage, t0) == (4 + 2 * G) * sizeof(int32_t), "field offsets below");
@@ -145,7 +145,7 @@ __device__ __forceinline__ DevStage load_stage(ConstWords stages, int idx) {
     st.t0 = w[4 + 2 * G]; st.nLo = w[5 + 2 * G]; st.nHi = w[6 + 2 * G]; st.nX = w[7 + 2 * G];
 #pragma unroll
     for (int k = 0; k <= kMaxRowBits; ++k) st.xo[k] = w[X + k];
-    st.nLoD = w[X + kMaxRowBits + 1]; st.nHiD = w[X + kMaxRowBits + 2];
+    st.nLoD = w[X + kMaxRowBits + 1]; st.nHiD = w[X + kMaxRowBits + 2]; st.reuse = w[X + kMaxRowBits + 3];
     return st;
 }
 
@@ -778,7 +778,20 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                 // work items: the ratio table first (64 columns: a wavefront shares its row bit, so
                 // the term ranges are scalar reads), then the column and the row tables
                 QK_MARK2(0);
-                if (!(fused && hoist)) for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
+                // The same terms as the diagonal stage before (the layers of a map at r >= 2), one chunk per sample: its
+                // tables are still there.  If that stage carried the product state, constants by SimArgs::init_h, they
+                // are divided out once (128 multiplications instead of 128 chains of a dozen).
+                const bool reuse = st.reuse != 0 && a.nlive == 0 && !fused && (st.reuse == 1 || (a.init_h && fuse_init && hoist));
+                if (reuse) {
+                    if (st.reuse == 2) {
+                        const double klo = 1.0 / (a.init_lo * a.init_chunk), khi = 1.0 / a.init_hi;
+                        for (uint32_t j = tid; j < nlo + nhi; j += T) {
+                            double2& e = j < nlo ? tlo[j] : thi[j - nlo];
+                            const double k = j < nlo ? klo : khi;
+                            e = make_double2(e.x * k, e.y * k);
+                        }
+                    }
+                } else if (!(fused && hoist)) for (uint32_t j = tid; j < n_rat + nlo + nhi; j += T) {
                     double fr = 1.0, fi = 0.0;
                     if (j < n_rat) {
                         const uint32_t c = j & (nlo - 1u);
@@ -1113,8 +1126,9 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         for (int k = 0; all_h && k < ps.n_init; ++k) all_h = c.mats[ps.mat_off + c.stages[ps.stage_off + k].gm[0]].gate == QK_H;
         return all_h;
     };
-    // ... and at 10 qubits the maps at r >= 2 as well (diagonal stages and layers of Hadamards only: radix-16 sweeps,
-    // 16 amplitudes per lane of a one-wave workgroup): ZZ r = 2 3.74 vs 4.40 ms; level at 9 qubits, behind at 8.
+    // ... and the maps at r >= 2 as well (diagonal stages and layers of Hadamards only), from 6 qubits: the layers'
+    // repeated diagonal stage builds its phase tables once (DevStage::reuse), at 10 qubits the Hadamards go 16
+    // amplitudes per lane.  ZZ r = 2, 4 GiB: 10 qubits 3.03 vs 4.3 ms, 9: 4.70 vs 5.91, 8: 5.33 vs 6.20, 6: 14.9 vs 16.2.
     auto h_layers_shape = [&]() {
         if (c.passes.size() != 1) return false;
         const Pass& ps = c.passes[0];
@@ -1129,8 +1143,10 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         }
         return layers;
     };
-    const bool prefer_lds = !force_wave && ((direct_shape && (n >= 9 || (n >= 6 && all_h_init(c.passes[0])))) ||
-                                            (n == 10 && h_layers_shape()));
+    // (small batches stay where they were: the pre-pass is one more launch, 5-10 us of a 0.1-1 ms call)
+    const bool big = (N >> 22 >> 0) != 0 || (N << n) >= ((int64_t)1 << 22);
+    const bool prefer_lds = !force_wave && (big || n > kWaveMaxQubits) && ((direct_shape && (n >= 9 || (n >= 6 && all_h_init(c.passes[0])))) ||
+                                            (n >= 6 && h_layers_shape()));
     if (dt.wave && !rdm_dev && !force_lds && !prefer_lds) {
         WaveJob job{};
         job.prog = dt.wave;

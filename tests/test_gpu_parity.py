@@ -71,6 +71,19 @@ def test_statevectors_hadamard_layers(n, builder, repeats, N):
     assert np.abs(got - O.statevectors(oops, n, X)).max() < TOL_PSI
 
 
+@pytest.mark.parametrize("n,builder,repeats", [(6, "zz", 1), (8, "z", 1), (8, "zz", 2), (9, "zz", 3), (10, "zz", 2), (10, "custom1", 1)])
+def test_statevectors_small_width_large_batch(n, builder, repeats):
+    """Up to 10 qubits a batch of 2^22 amplitudes or more sends the maps (product state + diagonal stages + layers of
+    Hadamards) to the LDS kernel instead of the wave-resident one: rows sampled from such a batch against the oracle."""
+    N = (1 << 22) >> n
+    X = synth_X(N, n, "scaled", 400 + n)
+    circ, oops, _ = map_pairs(n, repeats)[builder]
+    got = HipFidelityKernel(circ).statevectors(X)
+    rows = np.unique(np.concatenate([np.arange(3), np.random.default_rng(n).integers(0, N, 40), [N - 2, N - 1]]))
+    assert np.abs(got[rows] - O.statevectors(oops, n, X[rows])).max() < TOL_PSI
+    assert np.abs(np.sum(np.abs(got) ** 2, axis=1) - 1.0).max() < 1e-12
+
+
 def _fresh_qubit_circuit(n):
     """First gates on high (non-local) qubits in every flavour the planner distinguishes."""
     x = qc.ParameterVector("x", 4)
