@@ -426,6 +426,22 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             ps.n_init = (int)inits.size();
         }
         ps.zero_in = mask_of(~active & ((n >= 32) ? 0xffffffffu : ((1u << n) - 1u)));
+        // Hadamards on distinct qubits commute: in a pass that takes them four to a sweep, each layer starts with the
+        // four qubits the diagonal sweep walks (virtual bits h .. h + 3), so that the first sweep of the layer can ride
+        // on the fused diagonal stage before it (sim_pass_kernel: with_h)
+        if (ps.maxh == 4 && ps.L >= ps.h + 4) {
+            auto is_h = [&](int sid) { return !seq[sid].diag && seq[sid].nd.kind == ST_U1 && seq[sid].nd.gate == QK_H; };
+            for (size_t b = 0; b < d.stage_ids.size();) {
+                size_t e = b;
+                while (e < d.stage_ids.size() && is_h(d.stage_ids[e])) ++e;
+                if (e > b)
+                    std::stable_partition(d.stage_ids.begin() + b, d.stage_ids.begin() + e, [&](int sid) {
+                        const int v = virt[seq[sid].nd.q0];
+                        return v >= ps.h && v < ps.h + 4;
+                    });
+                b = e > b ? e : b + 1;
+            }
+        }
         std::vector<int32_t> prev_diag_sig;
         int prev_diag_stage = -1;
         // angle programs by content: every gate carries its own program, the layers of a map repeat the same ones
