@@ -818,7 +818,57 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                 QK_MARK2(1);
                 lds_barrier();
                 QK_MARK2(2);
-                if (st.nX == 0) {
+                // The fused stage followed by the Hadamards on the four row qubits a thread of the diagonal sweep walks (the
+                // planner puts that group first in the layer): the thread's 16 amplitudes -- rows r0 .. r0 + 15 of its
+                // column -- are exactly one item of that radix-16 sweep, so they go through the butterflies in registers
+                // before they are written for the first time.  One LDS pass and one barrier less per layer.
+                bool with_h = false;
+                if constexpr (MAXG >= 3) {
+                    if (fused && !to_hbm && h == 6 && nrb - (a.lgT - 6) == 4 && s + 1 < a.n_stage) {
+                        const DevStage nx = load_stage(c_stages, s + 1);
+                        with_h = nx.kind == ST_U1 && nx.ng == 4 && nx.gv[0] == h && nx.gv[1] == h + 1 && nx.gv[2] == h + 2 &&
+                                 nx.gv[3] == h + 3;
+                    }
+                }
+                if (with_h) {
+                    if constexpr (MAXG >= 3) {
+                        const uint32_t c = tid & 63u, r0 = (uint32_t)(tid >> 6) << 4;
+                        const bool cross = st.nX != 0;
+                        double2 X = tlo[c];
+                        double2 rr0 = make_double2(1.0, 0.0), rr1 = rr0, rr2 = rr0, rr3 = rr0;
+                        if (cross) {
+                            for (int b = 4; b < nrb; ++b)
+                                if ((r0 >> b) & 1u) X = cmul(X, rat[((uint32_t)b << h) | c]);
+                            rr0 = rat[c]; rr1 = rat[(1u << h) | c]; rr2 = rat[(2u << h) | c]; rr3 = rat[(3u << h) | c];
+                        }
+                        double2 vv[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int g = i ^ (i >> 1);
+                            if (i > 0 && cross) {
+                                const int b = __builtin_ctz(i);
+                                double2 q = b == 0 ? rr0 : (b == 1 ? rr1 : (b == 2 ? rr2 : rr3));
+                                if (!((g >> b) & 1)) q.y = -q.y;
+                                X = cmul(X, q);
+                            }
+                            vv[g] = cmul(X, thi[r0 | (uint32_t)g]);
+                        }
+#pragma unroll
+                        for (int gb = 0; gb < 4; ++gb)
+#pragma unroll
+                            for (int k = 0; k < 16; ++k)
+                                if (!((k >> gb) & 1)) {
+                                    const int k1 = k | (1 << gb);
+                                    const double2 a0 = vv[k], a1 = vv[k1];
+                                    vv[k] = make_double2(a0.x + a1.x, a0.y + a1.y);
+                                    vv[k1] = make_double2(a0.x - a1.x, a0.y - a1.y);
+                                }
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            state[((r0 | (uint32_t)k) << h) | c] = make_double2(vv[k].x * 0.25, vv[k].y * 0.25);
+                        ++s;      // the sweep is done
+                    }
+                } else if (st.nX == 0) {
                     if (fused && to_hbm) {
                         for (uint32_t l = tid; l < nloc; l += T) store_direct(l, cmul(tlo[l & (nlo - 1u)], thi[l >> h]));
                     } else if (fused) {
@@ -843,48 +893,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                     if (kb > 1) rr1 = rat[(1u << h) | c];
                     if (kb > 2) rr2 = rat[(2u << h) | c];
                     if (kb > 3) rr3 = rat[(3u << h) | c];
-                    // The fused stage followed by the Hadamards on the four walked row qubits (the planner puts that group
-                    // first in the layer): the thread's 16 amplitudes -- rows r0 .. r0 + 15 of its column -- are exactly one
-                    // item of that radix-16 sweep, so they go through the butterflies in registers before they are
-                    // written for the first time.  One LDS pass and one barrier less per layer.
-                    bool with_h = false;
-                    if constexpr (MAXG >= 3) {
-                        if (fused && !to_hbm && kb == 4 && s + 1 < a.n_stage) {
-                            const DevStage nx = load_stage(c_stages, s + 1);
-                            with_h = nx.kind == ST_U1 && nx.ng == 4 && nx.gv[0] == h && nx.gv[1] == h + 1 && nx.gv[2] == h + 2 &&
-                                     nx.gv[3] == h + 3;
-                        }
-                    }
-                    if (with_h) {
-                        if constexpr (MAXG >= 3) {
-                            double2 vv[16];
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const int g = i ^ (i >> 1);
-                                if (i > 0) {
-                                    const int b = __builtin_ctz(i);
-                                    double2 q = b == 0 ? rr0 : (b == 1 ? rr1 : (b == 2 ? rr2 : rr3));
-                                    if (!((g >> b) & 1)) q.y = -q.y;
-                                    X = cmul(X, q);
-                                }
-                                vv[g] = cmul(X, thi[r0 | (uint32_t)g]);
-                            }
-#pragma unroll
-                            for (int gb = 0; gb < 4; ++gb)
-#pragma unroll
-                                for (int k = 0; k < 16; ++k)
-                                    if (!((k >> gb) & 1)) {
-                                        const int k1 = k | (1 << gb);
-                                        const double2 a0 = vv[k], a1 = vv[k1];
-                                        vv[k] = make_double2(a0.x + a1.x, a0.y + a1.y);
-                                        vv[k1] = make_double2(a0.x - a1.x, a0.y - a1.y);
-                                    }
-#pragma unroll
-                            for (int k = 0; k < 16; ++k)
-                                state[((r0 | (uint32_t)k) << h) | c] = make_double2(vv[k].x * 0.25, vv[k].y * 0.25);
-                            ++s;      // the sweep is done
-                        }
-                    } else if (kb >= 2 && !fused) {
+                    if (kb >= 2 && !fused) {
                         // Four rows at a time: X(r0 + i0 + j, c) = X(r0 + i0, c) * {1, rr0, rr1, rr0 rr1}[j].  The four
                         // amplitudes, their row factors and the products are independent of each other, so the LDS reads
                         // of a block are in flight together and the multiplications overlap -- with two waves per SIMD a

@@ -84,6 +84,31 @@ def test_statevectors_small_width_large_batch(n, builder, repeats):
     assert np.abs(np.sum(np.abs(got) ** 2, axis=1) - 1.0).max() < 1e-12
 
 
+@pytest.mark.parametrize("n", [10, 11, 12, 13])
+def test_statevectors_hadamard_layers_without_cross_terms(n):
+    """Layers of Hadamards between diagonal stages none of whose two-qubit terms straddles local bits 5 | 6 (no cross
+    table): the fused diagonal stage + first radix-16 sweep path in its plain form, three layers deep."""
+    x = qc.ParameterVector("x", n)
+    c = qc.QuantumCircuit(n)
+    for q in range(n):
+        c.h(q)
+    for rep in range(3):
+        for q in range(5):
+            c.cz(q, q + 1)                                  # two-qubit terms inside the low half (every qubit in one,
+        for q in range(6, n - 1):                           # or the planner multiplies its h p h p ... into one matrix)
+            c.cx(q, q + 1); c.p(x[q] * x[q + 1], q + 1); c.cx(q, q + 1)   # ... and inside the high half
+        for q in range(n):
+            c.p(x[q] * (1.0 + 0.25 * rep), q)
+        for q in range(n):
+            c.h(q)
+    c.cz(n - 1, n - 2)
+    X = synth_X(4, n, "scaled", 500 + n)
+    k = HipFidelityKernel(c)
+    got = k.statevectors(X)
+    assert k._circuit().num_passes == 1
+    assert np.abs(got - psi_from_compiled(c, X)).max() < TOL_PSI
+
+
 def _fresh_qubit_circuit(n):
     """First gates on high (non-local) qubits in every flavour the planner distinguishes."""
     x = qc.ParameterVector("x", 4)

@@ -28,7 +28,7 @@ def circuits(n):
         g, xi = genetic.to_quantum(genes, gd, n, 8, n, physical_qubits=list(range(n)), verbose=False)
         if g.num_parameters == n:
             extra["genome_g8"] = g
-    return {"h_only": h, "z_r1": hp, "zz_r1": fm.zz_featuremap(x, n, 1), "zz_r2": fm.zz_featuremap(x, n, 2),
+    return {"h_only": h, "z_r1": hp, "z_r2": fm.z_featuremap(x, n, 2), "zz_r1": fm.zz_featuremap(x, n, 1), "zz_r2": fm.zz_featuremap(x, n, 2),
             "custom1_r1": fm.custom1_featuremap(x, n, 1), "custom2_r1": fm.custom2_featuremap(x, n, 1), **extra}
 
 ap = argparse.ArgumentParser()
