@@ -77,7 +77,8 @@ def test_multi_job_launch_matches_plan():
         assert np.abs(buf.cpu().numpy() - Kref[t.b0:t.b1, t.a0:t.a1]).max() < 1e-12
 
 
-@pytest.mark.parametrize("n,N,fused", [(1, 5, True), (3, 70, True), (9, 33, True), (12, 9, True), (14, 4, False)])
+@pytest.mark.parametrize("n,N,fused", [(1, 5, True), (3, 70, True), (9, 33, True), (10, 17, True), (11, 13, True), (12, 9, True), (13, 5, True),
+                                       (14, 4, False)])
 def test_fused_simulate_rdm1(n, N, fused):
     """qk_simulate_rdm1_dev: the RDMs come straight from the LDS-resident state (no Psi in HBM) when
     the circuit is one chunk per sample; otherwise through the workspace path.  Same numbers."""
