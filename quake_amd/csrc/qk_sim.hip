@@ -43,6 +43,7 @@ struct SimArgs {
     int init_h;
     double init_lo, init_hi, init_chunk;
     int dep_bytes;               // size of the deposit tables in LDS (a multiple of 16)
+    int h_load, h_store;         // the pass's first / last stage is a radix-16 Hadamard sweep that reads / writes HBM itself
     int n_stage, n_expr, n_mat, n_term;
     int staged;                                // the pass's DevExpr records (destinations of the angles) are copied to LDS
     int red_off;                               // fused-RDM scratch: offset in doubles from the end of the phase tables
@@ -382,6 +383,64 @@ __device__ __forceinline__ void sweep_h16(double2* state, const DevStage& st, ui
     }
 }
 
+// The same sweep at either end of a pass.  ld(l) / stf(l, v): where the amplitudes come from and go to -- the LDS image, or (a pass's first / last sweep, targets
+// above bit 3 so that 16 lanes still cover 256 consecutive bytes) the statevector in HBM directly.
+template <class Ld, class St>
+__device__ __forceinline__ void sweep_h16_io(const DevStage& st, uint32_t nloc, int tid, int T, Ld ld, St stf) {
+    uint32_t lm[4], off[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) lm[g] = (1u << st.gv[g]) - 1u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o |= (((uint32_t)k >> g) & 1u) << st.gv[g];
+        off[k] = o;
+    }
+    const bool low = st.gv[3] == 3;     // ascending and distinct: the targets are bits 0, 1, 2, 3
+    auto flip = [](double x, uint32_t m) { return __longlong_as_double(__double_as_longlong(x) ^ (long long)((uint64_t)m << 32)); };
+    const uint32_t items = nloc >> 4;
+    for (uint32_t i = tid; i < items; i += T) {
+        uint32_t b = i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b = ((b & ~lm[g]) << 1) | (b & lm[g]);
+        const uint32_t sw = low ? (i & 15u) : 0u;
+        double2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = ld(b | (off[k] ^ sw));
+        uint32_t mask[16];
+        if (low) {
+            const uint32_t b0 = (sw & 1u) << 31, b1 = (sw & 2u) << 30, b2 = (sw & 4u) << 29, b3 = (sw & 8u) << 28;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                mask[k] = ((k & 1) ? b0 : 0u) ^ ((k & 2) ? b1 : 0u) ^ ((k & 4) ? b2 : 0u) ^ ((k & 8) ? b3 : 0u);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) v[k] = make_double2(flip(v[k].x, mask[k]), flip(v[k].y, mask[k]));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (!((k >> g) & 1)) {
+                    const int k1 = k | (1 << g);
+                    const double2 a0 = v[k], a1 = v[k1];
+                    v[k] = make_double2(a0.x + a1.x, a0.y + a1.y);
+                    v[k1] = make_double2(a0.x - a1.x, a0.y - a1.y);
+                }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = make_double2(v[k].x * 0.25, v[k].y * 0.25);
+        if (low) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t m = mask[k] ^ mask[15];
+                v[k] = make_double2(flip(v[k].x, m), flip(v[k].y, m));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) stf(b | (off[k] ^ sw), v[k]);
+    }
+}
+
 template <int NG>
 __device__ __forceinline__ void sweep_u1_any(double2* state, const double2* mat, ConstWords mats, const DevStage& st,
                                              uint32_t nloc, int tid, int T) {
@@ -591,7 +650,7 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
             if (a.psi32) (a.psi32 + sample * a.D)[at] = make_float2((float)v.x, (float)v.y);
             else gpsi[at] = v;
         };
-        if (!a.first) {
+        if (!a.first && !a.h_load) {
             if (whi & a.zero_in) {
                 for (uint32_t l = tid; l < nloc; l += T) state[l] = make_double2(0.0, 0.0);
             } else {
@@ -824,7 +883,8 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                 // before they are written for the first time.  One LDS pass and one barrier less per layer.
                 bool with_h = false;
                 if constexpr (MAXG >= 3) {
-                    if (fused && !to_hbm && h == 6 && nrb - (a.lgT - 6) == 4 && s + 1 < a.n_stage) {
+                    if (fused && !to_hbm && h == 6 && nrb - (a.lgT - 6) == 4 && s + 1 < a.n_stage &&
+                        !(a.h_store && s + 1 == a.n_stage - 1)) {
                         const DevStage nx = load_stage(c_stages, s + 1);
                         with_h = nx.kind == ST_U1 && nx.ng == 4 && nx.gv[0] == h && nx.gv[1] == h + 1 && nx.gv[2] == h + 2 &&
                                  nx.gv[3] == h + 3;
@@ -950,7 +1010,16 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
                 else if (st.ng == 2) sweep_u1_any<2>(state, mat, c_mats, st, nloc, tid, T);
                 else if constexpr (MAXG >= 3) {
                     if (st.ng == 3) sweep_u1_any<3>(state, mat, c_mats, st, nloc, tid, T);
-                    else sweep_h16(state, st, nloc, tid, T);      // four Hadamards (the planner groups nothing else by four)
+                    else {      // four Hadamards (the planner groups nothing else by four)
+                        if (a.h_load && s == 0)
+                            sweep_h16_io(st, nloc, tid, T, [&](uint32_t l) { return gpsi[chunk_phys | dep_local(l)]; },
+                                         [&](uint32_t l, double2 v) { state[l] = v; });
+                        else if (a.h_store && s == a.n_stage - 1)
+                            sweep_h16_io(st, nloc, tid, T, [&](uint32_t l) { return state[l]; },
+                                         [&](uint32_t l, double2 v) { store_direct(l, v); });
+                        else
+                            sweep_h16(state, st, nloc, tid, T);
+                    }
                 }
             } else if (st.kind == ST_CX) {
                 const int vc = st.va, vt = st.vb;
@@ -1038,8 +1107,8 @@ __global__ void __launch_bounds__(512, (MAXG == 3 || RDM) ? 2 : 4) sim_pass_kern
             }
         lds_barrier();
         if constexpr (RDM) rdm1_from_lds(state, L, s_red, a.rdm + sample * (L * 4), tid, T);
-        if (a.direct || a.last_direct) {
-            // already stored by the (last) diagonal stage
+        if (a.direct || a.last_direct || a.h_store) {
+            // already stored by the last stage (a diagonal sweep or a radix-16 Hadamard sweep)
         } else if (a.psi32) {      // only on the last pass: intermediate passes stay FP64
             float2* g32 = a.psi32 + sample * a.D;
             for (uint32_t l = tid; l < nloc; l += T) {
@@ -1305,6 +1374,18 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         a.direct = direct ? 1 : 0;
         a.last_direct = (!direct && !rdm_dev && ps.zero_out == 0 && pi + 1 == c.passes.size() && ps.n_stage > 0 &&
                          c.stages[ps.stage_off + ps.n_stage - 1].kind == ST_DIAG) ? 1 : 0;
+        {
+            // a radix-16 Hadamard sweep at either end of the pass goes to HBM itself (no LDS image in between) when its
+            // targets lie above bit 3 and every amplitude of the chunk is live
+            auto h16 = [&](int k) {
+                const DevStage& st = c.stages[ps.stage_off + k];
+                return st.kind == ST_U1 && st.ng == 4 && st.gv[0] >= 4;
+            };
+            const bool reg3 = ps.maxg >= 3 && !ps.narrow;
+            const int first_stage = ps.first ? ps.n_init : 0;
+            a.h_store = (reg3 && !rdm_dev && ps.zero_out == 0 && ps.n_stage > first_stage && h16(ps.n_stage - 1)) ? 1 : 0;
+            a.h_load = (reg3 && !ps.first && ps.zero_in == 0 && ps.n_stage > 0 && h16(0) && !(a.h_store && ps.n_stage == 1)) ? 1 : 0;
+        }
         a.dep_bytes = (int)((4 * ((1u << ps.h) + (1u << (ps.L - ps.h))) + 15u) & ~15u);
         size_t lds = (direct ? (size_t)0 : ((size_t)16 << ps.L)) + (size_t)32 * ps.n_term + (size_t)64 * ps.n_mat + (size_t)a.dep_bytes +
                      (size_t)(hoist ? 32 : 16) * ((1u << ps.h) + (1u << (ps.L - ps.h))) +
