@@ -75,13 +75,13 @@ def align_kernel(kernel: HipFidelityKernel, dataset: np.ndarray, labels: np.ndar
                  seed: Optional[int] = None):
     """Same arguments and return shape as reference ``align_kernel`` (qsvm_tester.py:236-280):
     ``(aligned_kernel, opt_data)`` with ``opt_data = [result dict, history]``."""
-    from sklearn.model_selection import train_test_split
+    from .qsvm import get_subsample
 
     if not kernel.training_parameters:
         raise ValueError("the kernel has no training parameters to align")
     dataset, labels = np.asarray(dataset), np.asarray(labels)
     if labels.shape[0] > 500:       # reference :260-261 (get_subsample with seed 42)
-        dataset, labels = train_test_split(dataset, labels, train_size=500, random_state=42)[::2]
+        dataset, labels = get_subsample(dataset, labels, 500, 42)
     fmap, theta_params = kernel.feature_map, kernel.training_parameters
 
     def loss_pair(tp, tm):

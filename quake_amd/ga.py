@@ -334,10 +334,14 @@ class GeneticArtifacts:
 # --------------------------------------------------------------------------- #
 def generation_fitness(solutions, data_cv, data_labels, gate_dict, nb_features, gates_per_qubits, nb_qubits,
                        fit_fun: Callable, projected: bool = False, noise_std=None, depth_fn: Optional[Callable] = None,
-                       cv: int = 4, seed: int = 0, variant: str = "v3", coupling_map=None):
+                       cv: int = 4, seed: int = 0, variant: str = "v3", coupling_map=None, basis_gates=None,
+                       lower_fn: Optional[Callable] = None):
     """Fitness of many chromosomes at once: the body of the reference's ``fitness_func``
     (genetic_v3.py:604-666) with the kernels of the whole batch computed in one GPU call.
 
+    ``coupling_map`` serves the v4 / v5 decoders and, with ``basis_gates``, the lowering of the
+    ``without_kernel`` mode (``lower_fn(fmap, coupling_map, basis_gates, optimization_level=0)``, default
+    :func:`quake_amd.transpile.transpile`).
     Returns ``(fitness values, per-chromosome stats dicts or None)``."""
     from sklearn.model_selection import cross_val_score
     from sklearn.svm import SVC
@@ -348,8 +352,12 @@ def generation_fitness(solutions, data_cv, data_labels, gate_dict, nb_features, 
     decoded = [genetic.to_quantum(s, gate_dict, nb_features, gates_per_qubits, nb_qubits, verbose=False,
                                   variant=variant, coupling_map=coupling_map) for s in solutions]
     depth_of = depth_fn if depth_fn is not None else (lambda fmap: fmap.depth())
-    if "accuracy" not in inspect.signature(fit_fun).parameters:     # "without_kernel" mode (:710-725)
-        return [fit_fun(fmap) for fmap, _ in decoded], None
+    if "accuracy" not in inspect.signature(fit_fun).parameters:
+        # "without_kernel" mode (:710-725): the fitness function is handed the circuit as
+        # transpile(fmap, coupling_map, basis_gates, optimization_level=0) leaves it, not the decoder's
+        if lower_fn is None:
+            from .transpile import transpile as lower_fn
+        return [fit_fun(lower_fn(fmap, coupling_map, basis_gates, optimization_level=0)) for fmap, _ in decoded], None
     maps = [fmap for fmap, _ in decoded]
     xs = [data_cv[:, x_idxs] for _, x_idxs in decoded]
     if projected:
@@ -387,7 +395,7 @@ def genetic_instance(gene_space, data_cv, data_labels, backend, gate_dict, nb_fe
         values, stats = generation_fitness(solutions, data_cv, data_labels, gate_dict, nb_features, gates_per_qubits,
                                            nb_qubits, fit_fun, projected=projected, noise_std=noise_std,
                                            depth_fn=depth_fn, seed=counter["seed"], variant=variant,
-                                           coupling_map=coupling_map if variant != "v3" else None)
+                                           coupling_map=coupling_map, basis_gates=basis_gates)
         counter["seed"] += len(solutions)
         for k, sol in enumerate(solutions):
             st = stats[k] if stats is not None else None

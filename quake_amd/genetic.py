@@ -133,6 +133,28 @@ def to_quantum(
 
 
 # --------------------------------------------------------------------------- #
+# the genetic run's input range (reference genetic_v3.py:24-62)
+# --------------------------------------------------------------------------- #
+def get_subsample(dataset: np.ndarray, labels: np.ndarray, size: int, seed: int = 42, scaler=None):
+    """The GA's cross-validation set: scale with a FITTED ``MinMaxScaler``, drop every row that touches or
+    leaves the scaler's ``feature_range`` in any column (strictly: a value equal to a bound is an outlier
+    too), then a seeded ``train_test_split`` subsample of ``size`` rows (reference ``genetic_v3.py:24-62``).
+
+    With ``MinMaxScaler((0, 1))`` this is what puts the genome decoder's inputs in the OPEN interval
+    (0, 1), so every ``asin`` argument of :func:`_angle` stays inside (-1, 1).  ``scaler``
+    is required, as in the reference (which dereferences it unconditionally)."""
+    from sklearn.model_selection import train_test_split
+
+    if scaler is None:
+        raise AttributeError("'NoneType' object has no attribute 'feature_range' (pass a fitted MinMaxScaler)")
+    lo, hi = scaler.feature_range
+    scaled = scaler.transform(dataset)
+    inside = ~((scaled >= hi) | (scaled <= lo)).any(axis=1)
+    picked = train_test_split(scaled[inside], np.asarray(labels)[inside], train_size=size, random_state=seed)
+    return picked[0], picked[2]
+
+
+# --------------------------------------------------------------------------- #
 # population helpers (reference genetic_v3.py:65-212)
 # --------------------------------------------------------------------------- #
 def _nb_possible_gates(gate_dict: dict) -> int:

@@ -186,3 +186,74 @@ def qsvm_train(data_folder, train_folder, setup: dict):
     train_folder = Path(train_folder)
     train_folder.mkdir(parents=True, exist_ok=True)
     return qsvm_train_from_features(features, labels, train_folder, setup)
+
+
+# --------------------------------------------------------------------------- #
+# the comparison harness's two kernel consumers (reference qsvm_tester.py)
+# --------------------------------------------------------------------------- #
+def get_subsample(dataset, labels, size, seed):
+    """A seeded subsample of ``size`` rows (reference ``qsvm_tester.py:207-233``: the train half of
+    ``train_test_split(..., train_size=size, random_state=seed)``)."""
+    from sklearn.model_selection import train_test_split
+
+    return tuple(train_test_split(dataset, labels, train_size=size, random_state=seed)[::2])
+
+
+def _sorted_by_label(X: np.ndarray, y: np.ndarray):
+    """Rows reordered by ``np.argsort`` of the labels, features and labels promoted to one dtype: what the
+    reference gets by gluing the label column onto the features and sorting the rows on it
+    (``qsvm_tester.py:677-683``).  Same ``argsort`` call on the same values, so ties fall the same way."""
+    common = np.result_type(X.dtype, y.dtype)
+    y = np.asarray(y).astype(common, copy=False)
+    order = np.argsort(y)
+    return np.asarray(X).astype(common, copy=False)[order], y[order]
+
+
+def train_quantum(training_dataset, training_labels, val_dataset, test_dataset, quantum_kernels, cs):
+    """One precomputed-kernel SVC per quantum kernel on a label-sorted training set (reference
+    ``qsvm_tester.py:625-695``).  Returns ``(svcs, pred_train, pred_val, pred_test, kers)``; ``kers`` holds
+    the validation x train matrices when there are at most 200 training rows (reference :687-688).
+
+    The training set is re-sorted before every kernel, from the order the previous kernel left it in --
+    the reference reassigns its arguments inside the loop -- so row order, and with it the order of the
+    support vectors and of ``pred_train``, follows the reference for any number of kernels."""
+    from sklearn.svm import SVC
+
+    X, y = np.asarray(training_dataset), np.asarray(training_labels)
+    if len(cs) < len(quantum_kernels):
+        raise IndexError("cs needs one cost value per kernel")    # the reference indexes cs[q]
+    out = {"svcs": [], "train": [], "val": [], "test": [], "kers": []}
+    for kernel, c in zip(quantum_kernels, cs):
+        X, y = _sorted_by_label(X, y)
+        blocks = {"train": kernel.evaluate(x_vec=X),                       # the hot path, three shapes
+                  "val": kernel.evaluate(x_vec=val_dataset, y_vec=X),
+                  "test": kernel.evaluate(x_vec=test_dataset, y_vec=X)}
+        if y.shape[0] < 201:
+            out["kers"].append(np.real(blocks["val"]))
+        clf = SVC(kernel="precomputed", C=c).fit(blocks["train"], y)
+        out["svcs"].append(clf)
+        for split, K in blocks.items():
+            out[split].append(clf.predict(K))
+    return out["svcs"], out["train"], out["val"], out["test"], out["kers"]
+
+
+def cv_scores(train_dataset, train_labels, folds: int, kernels, training_size: Sequence[int], cs: Sequence[float],
+              seed: int = 2, on_score=None):
+    """Cross-validated accuracy of every kernel on seeded subsamples of growing size (reference
+    ``SvmsComparison.cv_scores``, ``qsvm_tester.py:1430-1471``; ``training_size`` / ``cs`` are the attributes
+    the method reads from its object, ``seed`` the literal 2 it passes to ``get_subsample``).
+
+    Returns ``(score[size, kernel, fold], mean[size, kernel], std[size, kernel])`` with
+    ``std = np.std(score, axis=2) / sqrt(folds)``.  ``on_score(score)`` is called after every block, where
+    the reference pickles its partial table (``score_TEMP.pkl``)."""
+    from sklearn.model_selection import cross_val_score
+    from sklearn.svm import SVC
+
+    score = np.zeros((len(training_size), len(kernels), folds))
+    for q, kernel in enumerate(kernels):
+        for i, size in enumerate(training_size):
+            subset, labels = get_subsample(train_dataset, train_labels, size, seed)
+            score[i, q] = cross_val_score(SVC(kernel="precomputed", C=cs[q]), kernel.evaluate(x_vec=subset), labels, cv=folds)
+            if on_score is not None:
+                on_score(score)
+    return score, np.mean(score, axis=2), np.std(score, axis=2) / np.sqrt(folds)

@@ -167,3 +167,43 @@ def transpiled_depth(circ: QuantumCircuit, coupling_map=None, basis_gates=None) 
     if coupling_map is not None:
         n = max([n] + [int(q) + 1 for pair in coupling_map for q in pair])
     return depth_of(lower(circ, coupling_map, basis_gates), n)
+
+
+class LoweredCircuit:
+    """What ``transpile(fmap, coupling_map, basis_gates, optimization_level=0)`` hands a ``without_kernel``
+    fitness function (reference genetic_v3.py:712; the shipped example's ``fit_fun(fmap)`` reads
+    ``fmap.count_ops()``, examples/genetic_featuremap_v3.py:77-85): the lowered, routed gate list with the
+    introspection calls a fitness function makes on a circuit.  Angles are not carried -- lowering keeps
+    gate kinds and positions only (module docstring) -- so this object cannot be simulated."""
+
+    def __init__(self, gates: Sequence[Gate], num_qubits: int):
+        self.data: List[Gate] = list(gates)
+        self.num_qubits = int(num_qubits)
+
+    def count_ops(self) -> dict:
+        counts: dict = {}
+        for name, _ in self.data:
+            counts[name] = counts.get(name, 0) + 1
+        return dict(sorted(counts.items(), key=lambda kv: -kv[1]))      # most frequent first, as qiskit orders it
+
+    def depth(self) -> int:
+        return depth_of(self.data, self.num_qubits)
+
+    def size(self) -> int:
+        return len(self.data)
+
+    def num_nonlocal_gates(self) -> int:
+        return sum(1 for _, qs in self.data if len(qs) > 1)
+
+    def __len__(self) -> int:
+        return len(self.data)
+
+
+def transpile(circ: QuantumCircuit, coupling_map=None, basis_gates=None, optimization_level: int = 0) -> LoweredCircuit:
+    """Stand-in for ``qiskit.transpile`` at the one place the reference passes its RESULT on rather than
+    taking ``.depth()`` of it (genetic_v3.py:712).  ``optimization_level`` is accepted for signature
+    compatibility; the lowering is the one described in the module docstring at every level."""
+    n = circ.num_qubits
+    if coupling_map is not None:
+        n = max([n] + [int(q) + 1 for pair in coupling_map for q in pair])
+    return LoweredCircuit(lower(circ, coupling_map, basis_gates), n)

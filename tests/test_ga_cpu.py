@@ -141,3 +141,29 @@ def test_load_feature_files_checks(tmp_path):
     np.save(tmp_path / "features_test.npy", np.zeros((3, 2)))
     with pytest.raises(ValueError):
         qsvm.load_feature_files(tmp_path)
+
+
+def test_get_subsample_scales_drops_outliers_and_splits():
+    """reference genetic_v3.py:24-62: MinMax transform with a FITTED scaler, rows touching the range's
+    bounds dropped (>= / <=), seeded train_test_split subsample"""
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import MinMaxScaler
+    from quake_amd.genetic import get_subsample
+    rng = np.random.default_rng(5)
+    fit_on = rng.normal(size=(400, 6))
+    data = np.concatenate([fit_on[:300], 3.0 * rng.normal(size=(40, 6))])     # some rows leave the fitted range
+    labels = rng.integers(0, 2, size=data.shape[0])
+    scaler = MinMaxScaler((0, 1)).fit(fit_on)
+    X, y = get_subsample(data, labels, 100, seed=42, scaler=scaler)
+    assert X.shape == (100, 6) and y.shape == (100,)
+    assert X.min() > 0.0 and X.max() < 1.0            # the OPEN interval: asin arguments of the decoder stay inside (-1, 1)
+    # an independent statement of the same selection
+    S = scaler.transform(data)
+    keep = np.array([not any(v >= 1.0 or v <= 0.0 for v in row) for row in S])
+    assert 0 < keep.sum() < data.shape[0]             # rows that hold a fitted minimum / maximum go too
+    Xr, yr = train_test_split(S[keep], labels[keep], train_size=100, random_state=42)[::2]
+    assert np.array_equal(X, Xr) and np.array_equal(y, yr)
+    X2, _ = get_subsample(data, labels, 100, seed=7, scaler=scaler)
+    assert not np.array_equal(X, X2)
+    with pytest.raises(AttributeError):
+        get_subsample(data, labels, 10)

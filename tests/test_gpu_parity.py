@@ -84,6 +84,53 @@ def test_statevectors_small_width_large_batch(n, builder, repeats):
     assert np.abs(np.sum(np.abs(got) ** 2, axis=1) - 1.0).max() < 1e-12
 
 
+@pytest.mark.parametrize("n,builder,repeats,N", [
+    (11, "zz", 2, 8192), (12, "zz", 2, 4096), (12, "z", 3, 4096), (13, "zz", 2, 4096), (12, "custom1", 2, 4096),
+    (14, "zz", 2, 1024), (15, "zz_full", 2, 384), (16, "zz", 2, 192), (16, "custom1", 2, 192), (16, "zz", 1, 192),
+])
+def test_statevectors_many_items_per_workgroup(n, builder, repeats, N):
+    """the persistent workgroups of the LDS simulator at 11-16 qubits with SEVERAL items each -- phase
+    tables kept from one item to the next (DevStage::reuse), the angle prefetch, the per-workgroup deposit tables,
+    the h_load / h_store sweeps of two-pass circuits -- whereas the other tests of this file give a workgroup one
+    item at most.  The batch is simulated on the device (up to 512 MiB of Psi); first, last, middle and random rows
+    go to the host and against the oracle."""
+    import torch
+    from quake_amd import device as qdev
+    X = synth_X(N, n, "scaled", 600 + n + repeats)
+    circ, oops, _ = map_pairs(n, repeats)[builder]
+    dc = qdev.DeviceCircuit(circ)
+    items = N << max(0, n - 12)
+    assert items >= 2 * 1024, "every workgroup (at most 4 per CU x 256 CUs) must get two items or more"
+    psi = dc.simulate(torch.from_numpy(X).cuda())
+    rows = np.unique(np.concatenate([[0, 1, N // 2 - 1, N // 2, N - 2, N - 1], np.random.default_rng(n).integers(0, N, 10)]))
+    got = psi[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert np.abs(got - O.statevectors(oops, n, X[rows])).max() < TOL_PSI
+    norms = (psi.real ** 2 + psi.imag ** 2).sum(dim=1)
+    assert float((norms - 1.0).abs().max()) < 1e-12          # every row of the batch, not only the sampled ones
+    # the same rows simulated alone (one item per workgroup) give the same bits: nothing leaks between items
+    alone = dc.simulate(torch.from_numpy(np.ascontiguousarray(X[rows])).cuda()).cpu().numpy()
+    assert np.array_equal(alone, got)
+
+
+def test_statevectors_many_items_per_workgroup_genomes():
+    """... and the general sweeps (composite 2x2 matrices, CX, 512-thread passes) on 12-qubit GA genomes, 4096 rows"""
+    import torch
+    from quake_amd import device as qdev
+    gate_dict = {"single_non_parametric": ["Id", "H", "X", "SX"], "single_parametric": ["RX", "RY", "RZ"],
+                 "two_non_parametric": ["CX"], "two_parametric": []}
+    n, F, G, N = 12, 18, 8, 4096
+    pop = genetic.initial_population(2, n, G, gate_dict, F, rng=np.random.default_rng(77))
+    for genes in pop:
+        fmap, xi = genetic.to_quantum(genes, gate_dict, F, G, n, physical_qubits=list(range(n)), verbose=False)
+        oops, oxi = O.to_quantum(genes, gate_dict, F, G, n, physical_qubits=list(range(n)))
+        assert xi == oxi
+        X = synth_X(N, F, "unit", 612)[:, xi]
+        psi = qdev.DeviceCircuit(fmap).simulate(torch.from_numpy(np.ascontiguousarray(X)).cuda())
+        rows = np.unique(np.concatenate([[0, N // 2, N - 1], np.random.default_rng(5).integers(0, N, 9)]))
+        got = psi[torch.from_numpy(rows).cuda()].cpu().numpy()
+        assert np.abs(got - O.statevectors(oops, n, X[rows])).max() < TOL_PSI
+
+
 @pytest.mark.parametrize("n", [10, 11, 12, 13])
 def test_statevectors_hadamard_layers_without_cross_terms(n):
     """Layers of Hadamards between diagonal stages none of whose two-qubit terms straddles local bits 5 | 6 (no cross

@@ -101,3 +101,67 @@ def test_genetic_fitness_matches_oracle(pins, data8, data_labels):
     v2, s2 = genetic.fitness(p["genes"], data8, data_labels, p["gate_dict"], 8, 8, 4, fit, projected=True)
     Kp = O.projected_kernel(ops, 4, data8[:, xi], 1)
     assert abs(s2["offdiagonal_std"] - np.std(np.triu(Kp, 1))) < 1e-13
+
+
+def _kernel_pairs():
+    """(HIP kernel, oracle kernel) for two maps over two features"""
+    from quake_amd import featuremaps as fm
+    from quake_amd.circuit import ParameterVector
+    from quake_amd.kernels import make_kernels
+    x = ParameterVector("x", 2)
+    hip = make_kernels([fm.zz_featuremap(x, 2, 2), fm.custom2_featuremap(x, 2)], None)
+    ora = [OracleKernel(O.zz_featuremap(2, 2), 2), OracleKernel(O.custom2_featuremap(2, 1), 2)]
+    return hip, ora
+
+
+def test_train_quantum_matches_oracle():
+    """reference qsvm_tester.py:625-695: label-sorted training set, train / val x train / test x train
+    matrices, one precomputed-kernel SVC per kernel -- GPU kernels against oracle kernels through the
+    same plumbing, and the plumbing against a direct statement of what it must deliver"""
+    from sklearn.svm import SVC
+    (Xtr, ytr), (Xv, _), (Xt, _) = _toy(11, 150), _toy(12, 40), _toy(13, 30)
+    Xtr, Xv, Xt = (np.clip(a, -1.5, 1.5) for a in (Xtr, Xv, Xt))
+    hip, ora = _kernel_pairs()
+    cs = [1.0, 10.0]
+    got = qsvm.train_quantum(Xtr, ytr, Xv, Xt, hip, cs)
+    ref = qsvm.train_quantum(Xtr, ytr, Xv, Xt, ora, cs)
+    for g, r in zip(got[1:4], ref[1:4]):
+        for a, b in zip(g, r):
+            assert np.array_equal(a, b)
+    assert len(got[4]) == 2 and got[4][0].shape == (40, 150)          # 150 training rows < 201: val matrices kept
+    assert np.abs(got[4][0] - ref[4][0]).max() < 1e-12
+    # the plumbing itself: rows sorted by label (all zeros first), fitted on the sorted matrix
+    order = np.argsort(ytr)
+    Xs, ys = Xtr[order], ytr[order]
+    assert np.all(np.diff(ys) >= 0)
+    K = O.evaluate(ora[0].ops, 2, Xs)
+    clf = SVC(kernel="precomputed", C=cs[0]).fit(K, ys)
+    assert np.array_equal(got[1][0], clf.predict(K))
+    assert np.array_equal(got[2][0], clf.predict(O.evaluate(ora[0].ops, 2, Xv, Xs)))
+    assert np.array_equal(got[3][0], clf.predict(O.evaluate(ora[0].ops, 2, Xt, Xs)))
+    assert np.array_equal(got[0][0].support_, clf.support_) and got[0][1].C == 10.0
+    # more than 200 training rows: no matrices are kept (reference :687-688)
+    big = qsvm.train_quantum(*_toy(14, 220), Xv, Xt, hip[:1], cs)
+    assert big[4] == [] and big[1][0].shape == (220,)
+    with pytest.raises(IndexError):
+        qsvm.train_quantum(Xtr, ytr, Xv, Xt, hip, [1.0])
+
+
+def test_cv_scores_matches_oracle():
+    """reference qsvm_tester.py:1430-1471: seeded subsamples (seed 2) of growing size, cross_val_score per
+    kernel and size, std = np.std / sqrt(folds)"""
+    from sklearn.model_selection import cross_val_score, train_test_split
+    from sklearn.svm import SVC
+    X, y = _toy(21, 200)
+    X = np.clip(X, -1.5, 1.5)
+    hip, ora = _kernel_pairs()
+    sizes, cs, folds = [40, 90], [1.0, 100.0], 3
+    seen = []
+    score, mean, std = qsvm.cv_scores(X, y, folds, hip, sizes, cs, on_score=lambda s: seen.append(s.copy()))
+    oscore, omean, ostd = qsvm.cv_scores(X, y, folds, ora, sizes, cs)
+    assert score.shape == (2, 2, 3) and np.array_equal(score, oscore)
+    assert np.array_equal(mean, omean) and np.array_equal(std, ostd) and len(seen) == 4
+    sub, lab = train_test_split(X, y, train_size=90, random_state=2)[::2]
+    direct = cross_val_score(SVC(kernel="precomputed", C=100.0), O.evaluate(ora[1].ops, 2, sub), lab, cv=folds)
+    assert np.array_equal(score[1, 1], direct)
+    assert np.allclose(std, np.std(score, axis=2) / np.sqrt(folds)) and np.allclose(mean, score.mean(axis=2))
