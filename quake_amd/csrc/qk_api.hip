@@ -4,6 +4,7 @@
 #include <cstdio>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -22,11 +23,37 @@ int fail(int code, const std::string& msg) {
 }
 
 namespace {
+// Where the wall time of the calling thread's last qk_evaluate / qk_evaluate_f32 went (seconds; development hook
+// qk_evaluate_profile, used by bench.py to itemise the PCIe-inclusive call of SURVEY.md 8d):
+//   [0] device allocations   [1] host-to-device copies of X / Y   [2] enqueueing the simulations and Gram bands
+//   [3] waiting for the bands while copying the finished ones to the host (the device work, with all copies but
+//       the last band's hidden behind it)   [4] what remained after the last kernel had finished: the last band's
+//       copy   [5] releasing the device buffers   [6] the whole call
+struct EvalProfile { double t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+thread_local EvalProfile g_profile;
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct Lap {      // adds the time since the previous lap to a slot of the profile
+    double last = now_s();
+    void to(int slot) { const double t = now_s(); g_profile.t[slot] += t - last; last = t; }
+};
+
 // RAII device buffer for the host-pointer entry points
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { release(); }
+    void release() {
+        if (!p) return;
+        const double t0 = now_s();
+        (void)hipFree(p);
+        g_profile.t[5] += now_s() - t0;
+        p = nullptr;
+    }
+    hipError_t alloc(size_t bytes) {
+        const double t0 = now_s();
+        const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        g_profile.t[0] += now_s() - t0;
+        return e;
+    }
 };
 
 int check_device() {
@@ -40,7 +67,9 @@ int check_device() {
 int upload_X(const double* X, int64_t N, int F, DevBuf& buf) {
     if (F == 0 || N == 0) return QK_OK;
     QK_HIP(buf.alloc((size_t)N * F * sizeof(double)));
+    const double t0 = now_s();
     QK_HIP(hipMemcpy(buf.p, X, (size_t)N * F * sizeof(double), hipMemcpyHostToDevice));
+    g_profile.t[1] += now_s() - t0;
     return QK_OK;
 }
 }  // namespace
@@ -264,6 +293,7 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
     }
     // two side streams per device, created once and kept (a host application's own streams are left alone: no
     // device-wide synchronisation here)
+    Lap lap;
     hipStream_t compute = nullptr, copy = nullptr;
     int rc = side_streams(&compute, &copy);
     if (rc) return rc;
@@ -315,9 +345,14 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
         if (hipEventRecord(e, compute) != hipSuccess) rc = fail(QK_ERR_HIP, "gram_to_host: cannot record event");
     }
     // every launch is queued; now drain band by band while the later bands compute
+    lap.to(2);
     size_t b = first_band_event;
     for (int64_t r0 = 0; r0 < N && rc == QK_OK; r0 += band, ++b) {
         const int64_t r1 = std::min(N, r0 + band);
+        if (r1 >= N) {      // the last band: from here on no kernel runs behind the copy
+            if (hipEventSynchronize(done[b]) != hipSuccess) rc = fail(QK_ERR_HIP, "gram_to_host: synchronisation failed");
+            lap.to(3);
+        }
         if (hipStreamWaitEvent(copy, done[b], 0) != hipSuccess ||
             hipMemcpyAsync(K_host + r0 * M, K + r0 * M, (size_t)(r1 - r0) * M * sizeof(double), hipMemcpyDeviceToHost, copy) !=
                 hipSuccess ||
@@ -327,6 +362,7 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
     // on an error path kernels may still be running on the buffers the caller is about to free
     if (hipStreamSynchronize(compute) != hipSuccess && rc == QK_OK) rc = fail(QK_ERR_HIP, "gram_to_host: synchronisation failed");
     if (hipStreamSynchronize(copy) != hipSuccess && rc == QK_OK) rc = fail(QK_ERR_HIP, "gram_to_host: synchronisation failed");
+    lap.to(4);
     cleanup();
     return rc;
 }
@@ -345,18 +381,36 @@ extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, cons
     if (N == 0 || M == 0) return QK_OK;
     int rc = check_device();
     if (rc) return rc;
+    g_profile = EvalProfile();
+    const double t_begin = now_s();
     const int F = c->n_params;
     const int64_t D = (int64_t)1 << c->n_qubits;
-    DevBuf dX, dY, dPx, dPy;
-    if ((rc = upload_X(X, N, F, dX))) return rc;
-    QK_HIP(dPx.alloc((size_t)N * D * 16));
-    if ((rc = qk_simulate_dev(c, (const double*)dX.p, N, F, dPx.p, nullptr))) return rc;
-    if (!sym) {
-        if ((rc = upload_X(Y, M, F, dY))) return rc;
-        QK_HIP(dPy.alloc((size_t)M * D * 16));
-        if ((rc = qk_simulate_dev(c, (const double*)dY.p, M, F, dPy.p, nullptr))) return rc;
+    {
+        DevBuf dX, dY, dPx, dPy;
+        if ((rc = upload_X(X, N, F, dX))) return rc;
+        QK_HIP(dPx.alloc((size_t)N * D * 16));
+        double t0 = now_s();
+        if ((rc = qk_simulate_dev(c, (const double*)dX.p, N, F, dPx.p, nullptr))) return rc;
+        g_profile.t[2] += now_s() - t0;
+        if (!sym) {
+            if ((rc = upload_X(Y, M, F, dY))) return rc;
+            QK_HIP(dPy.alloc((size_t)M * D * 16));
+            t0 = now_s();
+            if ((rc = qk_simulate_dev(c, (const double*)dY.p, M, F, dPy.p, nullptr))) return rc;
+            g_profile.t[2] += now_s() - t0;
+        }
+        rc = gram_to_host(dPx.p, N, sym ? nullptr : dPy.p, M, D, false, K_host);
     }
-    return gram_to_host(dPx.p, N, sym ? nullptr : dPy.p, M, D, false, K_host);
+    g_profile.t[6] = now_s() - t_begin;
+    return rc;
+}
+
+// Development hook (not in the public header): the itemised wall time of the calling thread's last qk_evaluate /
+// qk_evaluate_f32, see EvalProfile.
+extern "C" int qk_evaluate_profile(double* out, int len) {
+    if (!out || len < 1) return QK_ERR_INVALID;
+    for (int k = 0; k < len && k < 8; ++k) out[k] = g_profile.t[k];
+    return QK_OK;
 }
 
 extern "C" int qk_evaluate_f32(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,

@@ -49,13 +49,14 @@ struct GramJobDev {
     int64_t ma, nb, ldk, ldkt;
     int32_t flags;
     int32_t tiles_m, tiles_n;  // block tiles
-    int64_t block_begin;       // first workgroup of this job
+    int64_t tile_begin;        // position of this job's first tile in the launch's list of live tiles
     int64_t live;              // number of tiles that have to be computed
 };
 
 struct GramArgs {
     GramJobDev job[QK_GRAM_MAX_JOBS];
     int n_jobs;
+    uint32_t total_live;   // live tiles of all jobs together: ONE list, cut into groups without regard to job boundaries
     int lr, lc;  // log2 of the macro-tile shape in block tiles (rows, columns): 4 x 8 for 128 x 128 tiles
     int64_t D;  // amplitudes per row
     int64_t ld; // row stride of A and B in amplitudes (>= D)
@@ -93,26 +94,34 @@ __device__ __forceinline__ uint32_t gram_div_small(uint32_t x, uint32_t d) {   /
     }
 }
 
-__device__ __forceinline__ bool gram_tile_of(const GramJobDev& J, const uint32_t lb, const int lr, const int lc, int& ti, int& tj) {
+// Position `lb` of the launch (block id) -> index in the launch's list of live tiles; false for padding positions.
+// The jobs of a launch form ONE list (job after job): a group of 2^(lr+lc) tiles may straddle two jobs, but no
+// round of 8 groups is left partial between jobs.  (Each job padded to whole rounds of its own -- the first version --
+// left the 32 tiles of a small symmetric block running alone next to 480 empty positions, after which the next job's
+// workgroups start in two shifts and the cohorts of an XCD no longer walk their rows together for the rest of the
+// launch: a band of the host path or a rank's share ran 5-6 % below the rate of one large job, tools/gram_shapes.py.)
+__device__ __forceinline__ bool gram_position_to_tile(const uint32_t live, const uint32_t lb, const int lr, const int lc, uint32_t& t) {
     const uint32_t xcd = lb & 7u;
     const uint32_t seq = lb >> 3;                      // position in this XCD's stream
     const int g = lr + lc;
-    const uint32_t live = (uint32_t)J.live;
     const uint32_t full = live >> (g + 3);             // rounds of 8 whole groups
-    uint32_t t;                                        // index in the job's list of live tiles
     if ((seq >> g) < full) {
         t = ((((seq >> g) << 3) + xcd) << g) + (seq & ((1u << g) - 1u));
-    } else {
-        // The last, partial round is dealt out evenly, an eighth to each XCD (dealt by whole groups, 2080 tiles
-        // = 32.5 groups of 64 at N = 4096 left one XCD with 288 tiles and seven with 256: the launch took 9 tile
-        // times per CU instead of 8.1).
-        const uint32_t rest = live - (full << (g + 3));
-        const uint32_t chunk = (rest + 7u) >> 3;
-        const uint32_t within = seq - (full << g);
-        if (within >= chunk) return false;
-        t = (full << (g + 3)) + xcd * chunk + within;
-        if (t >= live) return false;
+        return true;
     }
+    // The last, partial round is dealt out evenly, an eighth to each XCD (dealt by whole groups, 2080 tiles
+    // = 32.5 groups of 64 at N = 4096 left one XCD with 288 tiles and seven with 256: the launch took 9 tile
+    // times per CU instead of 8.1).
+    const uint32_t rest = live - (full << (g + 3));
+    const uint32_t chunk = (rest + 7u) >> 3;
+    const uint32_t within = seq - (full << g);
+    if (within >= chunk) return false;
+    t = (full << (g + 3)) + xcd * chunk + within;
+    return t < live;
+}
+
+// Tile number t of job J's list of live tiles -> block tile (ti, tj).
+__device__ __forceinline__ void gram_tile_of(const GramJobDev& J, uint32_t t, const int lr, const int lc, int& ti, int& tj) {
     const uint32_t br = 1u << lr, TMt = (uint32_t)J.tiles_m, TNt = (uint32_t)J.tiles_n;
     uint32_t lo = 0, hi = ((TMt + br - 1u) >> lr) - 1u;    // the band: binary search, every band before `hi` is full
     if (!(J.flags & QK_GRAM_SYMMETRIC)) {
@@ -126,7 +135,7 @@ __device__ __forceinline__ bool gram_tile_of(const GramJobDev& J, const uint32_t
         const uint32_t c = rb == br ? idx >> lr : gram_div_small(idx, rb);
         tj = (int)c;
         ti = (int)((lo << lr) + (idx - c * rb));
-        return true;
+        return;
     }
     // symmetric (square tiles): band m holds, for the columns c >= m * br, the rows m * br .. min(c, m * br + rb - 1):
     // rb (TNt - m br) - rb (rb - 1) / 2 tiles; m full bands hold m (br TNt - br (br - 1) / 2) - br^2 m (m - 1) / 2
@@ -153,7 +162,6 @@ __device__ __forceinline__ bool gram_tile_of(const GramJobDev& J, const uint32_t
     }
     ti = (int)(first + r);
     tj = (int)(first + k);
-    return true;
 }
 
 // The job record is read through a pointer to the kernel-argument segment: through the by-value struct the
@@ -161,16 +169,19 @@ __device__ __forceinline__ bool gram_tile_of(const GramJobDev& J, const uint32_t
 // kernel locates its next tile with a full register file); through the pointer it loads the one it needs.
 typedef const __attribute__((address_space(4))) GramArgs* gram_kargs_t;
 __device__ __forceinline__ bool gram_locate(gram_kargs_t ap, const uint32_t bid, GramJobDev& J, int& ti, int& tj) {
+    uint32_t t;
+    if (!gram_position_to_tile(ap->total_live, bid, ap->lr, ap->lc, t)) return false;
     const int nj = ap->n_jobs;
     int k = 0;
     for (int q = 1; q < nj; ++q)
-        if (bid >= (uint32_t)ap->job[q].block_begin) k = q;
+        if (t >= (uint32_t)ap->job[q].tile_begin) k = q;
     const __attribute__((address_space(4))) GramJobDev* s = &ap->job[k];
     J.A = s->A; J.B = s->B; J.K = s->K; J.KT = s->KT;
     J.ma = s->ma; J.nb = s->nb; J.ldk = s->ldk; J.ldkt = s->ldkt;
     J.flags = s->flags; J.tiles_m = s->tiles_m; J.tiles_n = s->tiles_n;
-    J.block_begin = s->block_begin; J.live = s->live;
-    return gram_tile_of(J, bid - (uint32_t)J.block_begin, ap->lr, ap->lc, ti, tj);
+    J.tile_begin = s->tile_begin; J.live = s->live;
+    gram_tile_of(J, t - (uint32_t)J.tile_begin, ap->lr, ap->lc, ti, tj);
+    return true;
 }
 // for a kernel whose only argument is GramArgs (offset 0 of the segment)
 __device__ __forceinline__ bool gram_locate(const GramArgs&, const int64_t bid, GramJobDev& J, int& ti, int& tj) {
@@ -909,8 +920,8 @@ gram_ring_kernel(GramArgs args) {
     unsigned int sync_members = 0, sync_epoch = 0;
     if (NST == 5 && args.sync) {
         // the cohort: 32 consecutive positions of one XCD label; how many of them hold a tile (as in gram_tile_of, 8 x 8 groups)
-        const uint32_t lb = blockIdx.x - (uint32_t)J.block_begin, seq = lb >> 3, xcd = lb & 7u;
-        const uint32_t live = (uint32_t)J.live, full = live >> 9;
+        const uint32_t lb = blockIdx.x, seq = lb >> 3, xcd = lb & 7u;
+        const uint32_t live = args.total_live, full = live >> 9;      // (as in gram_position_to_tile: the launch's one list)
         sync_members = 32;
         if ((seq >> 6) >= full) {
             const uint32_t rest = live - (full << 9), chunk = (rest + 7u) >> 3;
@@ -1578,6 +1589,7 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
     args.lr = lr;
     args.lc = lc;
     blocks = 0;
+    int64_t total = 0;     // live tiles so far
     int nj = 0;
     for (int k = 0; k < n_jobs; ++k) {
         const qk_gram_job& j = jobs[k];
@@ -1599,7 +1611,7 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
         d.flags = j.flags;
         d.tiles_m = (int32_t)((j.ma + bm - 1) / bm);
         d.tiles_n = (int32_t)((j.nb + bn - 1) / bn);
-        d.block_begin = blocks;
+        d.tile_begin = total;
         if (sym && bm != bn) return fail(QK_ERR_INVALID, std::string(who) + ": symmetric jobs need square tiles");
         const int br = 1 << lr;
         if (sym) {
@@ -1611,11 +1623,14 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
         } else {
             d.live = (int64_t)d.tiles_m * d.tiles_n;
         }
-        const int64_t per_group = (int64_t)1 << (lr + lc);
-        const int64_t groups = (d.live + per_group - 1) / per_group;
-        blocks += ((groups + 7) / 8) * 8 * per_group;  // whole rounds of 8 groups, one per XCD label
+        total += d.live;
     }
     args.n_jobs = nj;
+    const int64_t per_group = (int64_t)1 << (lr + lc);
+    const int64_t groups = (total + per_group - 1) / per_group;
+    blocks = ((groups + 7) / 8) * 8 * per_group;  // whole rounds of 8 groups, one per XCD label, over ALL jobs' tiles
+    if (total > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, std::string(who) + ": too many tiles; split the call");
+    args.total_live = (uint32_t)total;
     if (blocks > 0x7fffffffLL) return fail(QK_ERR_UNSUPPORTED, std::string(who) + ": too many tiles; split the call");
     return QK_OK;
 }

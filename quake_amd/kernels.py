@@ -187,11 +187,22 @@ class HipFidelityKernel:
                     f"y_vec has {y.shape[1]} dimensions, but feature map has {nf}.")
         return x, y
 
-    def evaluate(self, x_vec, y_vec=None) -> np.ndarray:
+    def evaluate(self, x_vec, y_vec=None, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Gram matrix, ``float64 [len(x_vec), len(y_vec or x_vec)]``, C-contiguous.
 
-        ``y_vec is None`` gives the symmetric matrix with an exact unit diagonal."""
+        ``y_vec is None`` gives the symmetric matrix with an exact unit diagonal.
+        ``out`` (an extension; the reference always returns a fresh array): a C-contiguous float64 array of the
+        result's shape that receives K and is returned.  A caller that evaluates again and again (a learning
+        curve, a GA) can keep ONE page-locked array from ``quake_amd._lib.host_empty`` and spare every call the
+        page-locking of a fresh one -- 32 GiB at the headline size."""
         x, y = self._validate(x_vec, y_vec)
+        if out is not None:
+            want = (x.shape[0], x.shape[0] if y is None else y.shape[0])
+            if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == want
+                    and out.flags.c_contiguous and out.flags.writeable):
+                raise ValueError(f"out must be a writable C-contiguous float64 array of shape {want}")
+            if self._shots is not None or (y is None and self._enforce_psd):
+                raise ValueError("out= is not supported with shots or enforce_psd")
         if self._shots is not None:
             # FidelityStatevectorKernel(shots=...): each entry becomes Binomial(shots, K_ij) / shots.
             # Sampled on the device (qk_kernel_noise_dev) for the symmetric matrix.
@@ -204,7 +215,7 @@ class HipFidelityKernel:
         lib = _lib.load()
         circ = self._circuit()
         n, m = x.shape[0], (x.shape[0] if y is None else y.shape[0])
-        K = _lib.host_empty((n, m))
+        K = out if out is not None else _lib.host_empty((n, m))
         _lib.check((lib.qk_evaluate if self._precision == "double" else lib.qk_evaluate_f32)(
             circ.handle, _lib.ptr(x), n,
             _lib.ptr(y) if y is not None else None, m, x.shape[1], _lib.ptr(K)))
