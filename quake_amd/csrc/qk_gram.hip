@@ -500,7 +500,7 @@ struct GramDmaCfg {
     static_assert(BM % (4 * WAVES) == 0 && BN % (4 * WAVES) == 0, "rows must split evenly over the waves");
 };
 
-constexpr int kSyncCounters = 1 << 16;
+constexpr int kSyncCounters = 1 << 18;
 static __device__ unsigned int g_sync_counters[kSyncCounters];   // pacing counters of the ring kernel (see there)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -1654,23 +1654,39 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
     }
     if (QK_GRAM_ABLATE & 128) args.trace = g_trace.load();
     // Pacing counters of the ring kernel (see gram_ring_kernel): one per cohort of 32 workgroups, cleared in stream
-    // order before the launch.  The table is one static array per device: two launches that overlap on one device
-    // (different streams) clear each other's counters, which costs the earlier one bounded waits (8.5 us per meeting,
-    // a meeting every 0.4 ms) and nothing else -- the counters pace, they do not guard data.
-    // QK_GRAM_PACE=0 turns pacing off, any other value is log2 of the stage-loop trips between meetings (A/B runs).
+    // order before the launch.  The table is one static array per device, handed out as a ring: every launch takes
+    // the next slice of it (a ticket drawn here, under a mutex, in the order the host enqueues), so launches that
+    // are in flight together on one device -- two streams of a host application, the chromosome batches of a GA
+    // next to something else -- never clear or count on each other's counters.  A slice is reused only after the
+    // whole ring (2^18 counters = 16 launches of the headline size) has been handed out since; even then a clash
+    // costs bounded waits and nothing else: the counters pace, they do not guard data.
+    // QK_GRAM_PACE=0 turns pacing off, any other value is log2 of the stage-loop trips between meetings;
+    // QK_GRAM_PACE_SHARED=1 gives every launch the slice at offset 0, the behaviour before round 3 (A/B runs).
     static const int pace_env = std::getenv("QK_GRAM_PACE") ? std::atoi(std::getenv("QK_GRAM_PACE")) : 7;
+    static const bool pace_shared = std::getenv("QK_GRAM_PACE_SHARED") && std::atoi(std::getenv("QK_GRAM_PACE_SHARED")) != 0;
     args.sync_shift = pace_env > 0 ? pace_env : 7;
-    if (pace_env > 0 && vi == kRing5Variant && D >= 4096 && blocks / 32 + 8 <= kSyncCounters) {
-        static std::atomic<unsigned int*> table[64];
+    const int64_t need = ((blocks / 32 + 8) + 63) / 64 * 64;
+    if (pace_env > 0 && vi == kRing5Variant && D >= 4096 && need <= kSyncCounters) {
+        static std::mutex mu;
+        static unsigned int* table[64] = {};
+        static int64_t next[64] = {};
         int dev = 0;
         QK_HIP(hipGetDevice(&dev));
-        unsigned int* cnt = (dev >= 0 && dev < 64) ? table[dev].load() : nullptr;
-        if (!cnt) {
-            QK_HIP(hipGetSymbolAddress((void**)&cnt, HIP_SYMBOL(g_sync_counters)));
-            if (dev >= 0 && dev < 64) table[dev] = cnt;
+        if (dev < 0 || dev >= 64) return fail(QK_ERR_UNSUPPORTED, "qk_gram_jobs_dev: device index out of range");
+        unsigned int* cnt = nullptr;
+        int64_t off = 0;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!table[dev]) QK_HIP(hipGetSymbolAddress((void**)&table[dev], HIP_SYMBOL(g_sync_counters)));
+            cnt = table[dev];
+            if (!pace_shared) {
+                if (next[dev] + need > kSyncCounters) next[dev] = 0;
+                off = next[dev];
+                next[dev] += need;
+            }
         }
-        QK_HIP(hipMemsetAsync(cnt, 0, (size_t)(blocks / 32 + 8) * sizeof(unsigned int), (hipStream_t)stream));
-        args.sync = cnt;
+        QK_HIP(hipMemsetAsync(cnt + off, 0, (size_t)need * sizeof(unsigned int), (hipStream_t)stream));
+        args.sync = cnt + off;
     }
     V.launch(args, (unsigned)blocks, (hipStream_t)stream);
     QK_HIP(hipGetLastError());
