@@ -11,7 +11,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = PKG_DIR / "libquake_hip.so"
-SOURCES = ["qk_api.hip", "qk_circuit.cpp", "qk_sim.hip", "qk_wave.hip", "qk_gram.hip", "qk_pqk.hip", "qk_stats.hip"]
+SOURCES = ["qk_api.hip", "qk_circuit.cpp", "qk_sim.hip", "qk_wave.hip", "qk_reg.hip", "qk_gram.hip", "qk_pqk.hip", "qk_stats.hip"]
 
 
 def hipcc() -> str:
@@ -25,7 +25,7 @@ def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "qk_common.h", CSRC / "qk_rdm.h", CSRC / "qk_math.h", CSRC / "qk_wave.h", INCLUDE / "quake_hip.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "qk_common.h", CSRC / "qk_rdm.h", CSRC / "qk_math.h", CSRC / "qk_wave.h", CSRC / "qk_reg.h", INCLUDE / "quake_hip.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 
@@ -39,7 +39,8 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> 
     # qk_wave.hip keeps a statevector in registers across a large scalar dispatch; two middle-end transforms
     # defeat that (common-code sinking merges the per-qubit arms into pointer selects, the AMDGPU alloca-to-vector
     # pass turns the amplitude array into one 32-register tuple): both off for that file
-    per_file = {"qk_wave.hip": ["-mllvm", "-simplifycfg-sink-common=false", "-mllvm", "-disable-promote-alloca-to-vector"]}
+    keep_in_regs = ["-mllvm", "-simplifycfg-sink-common=false", "-mllvm", "-disable-promote-alloca-to-vector"]
+    per_file = {"qk_wave.hip": keep_in_regs, "qk_reg.hip": keep_in_regs}      # (qk_reg.hip: the same structure, 16 amplitudes per lane)
     procs = []
     for s in SOURCES:
         obj = objdir / (s.rsplit(".", 1)[0] + ".o")

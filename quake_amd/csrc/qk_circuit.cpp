@@ -13,10 +13,12 @@
 //   3. splits the stage list into passes whose non-diagonal gates only touch
 //      "local" qubits (<= 13, the part of the state one workgroup keeps in LDS).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
 #include "qk_common.h"
+#include "qk_reg.h"
 #include "qk_wave.h"
 
 namespace qk {
@@ -585,6 +587,271 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         ps.n_mat = (int)c.mats.size() - ps.mat_off;
         ps.n_comp = (int)c.comps.size() - ps.comp_off;
         c.passes.push_back(ps);
+    }
+
+    // ---- 4. the register-resident program (10 to 13 qubits, one pass, every qubit local: qk_reg.h) ----------
+    c.reg_blob.clear();
+    if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1 && c.passes[0].L == n) {
+        // Single-qubit gates on distinct qubits with nothing between them commute: inside such a run the gates are
+        // taken in ascending qubit order, so that a layer of gates fills whole groups of four neighbouring qubits and
+        // the groups with the low qubits come first (the last layout then keeps the low qubits in the thread index:
+        // the final stores cover consecutive amplitudes).
+        std::vector<int> order(seq.size());
+        for (size_t k = 0; k < seq.size(); ++k) order[k] = (int)k;
+        auto is_u1 = [&](int id) { return !seq[id].diag && seq[id].nd.kind == ST_U1; };
+        for (size_t b = 0; b < order.size();) {
+            size_t e = b;
+            uint32_t used = 0;
+            while (e < order.size() && is_u1(order[e]) && !((used >> seq[order[e]].nd.q0) & 1u)) used |= 1u << seq[order[e++]].nd.q0;
+            if (e > b + 1) std::stable_sort(order.begin() + b, order.begin() + e, [&](int x, int y) { return seq[x].nd.q0 < seq[y].nd.q0; });
+            b = e > b ? e : b + 1;
+        }
+        // register qubits per layout: 3 = 8 amplitudes per thread and twice the threads (twice the waves per CU for the
+        // same LDS: the kernel is bound by latency, not by issue); QK_REG_RB overrides (A/B runs)
+        static const int rb_env = std::getenv("QK_REG_RB") ? std::atoi(std::getenv("QK_REG_RB")) : 0;
+        const int RB = (rb_env == 3 || rb_env == 4) ? rb_env : 4;
+        struct SegDraft { std::vector<int> bits, ids; };
+        std::vector<SegDraft> sd(1);
+        for (int id : order) {
+            const Proto& p = seq[id];
+            std::vector<int> need;
+            if (!p.diag) {
+                if (p.nd.kind == ST_U1) need = {p.nd.q0};
+                else if (p.nd.kind == ST_CX) need = {p.nd.q1};
+                else need = {p.nd.q0, p.nd.q1};
+            }
+            std::vector<int> b2 = sd.back().bits;
+            for (int q : need)
+                if (std::find(b2.begin(), b2.end(), q) == b2.end()) b2.push_back(q);
+            if ((int)b2.size() > RB) {
+                sd.push_back(SegDraft{});
+                b2 = need;
+            }
+            sd.back().bits = b2;
+            sd.back().ids.push_back(id);
+        }
+        for (SegDraft& g : sd) {      // fill the group with the highest qubits it does not hold yet
+            for (int q = n - 1; q >= 0 && (int)g.bits.size() < RB; --q)
+                if (std::find(g.bits.begin(), g.bits.end(), q) == g.bits.end()) g.bits.push_back(q);
+            std::sort(g.bits.begin(), g.bits.end());
+        }
+        std::vector<RegSeg> segs;
+        std::vector<RegOp> rops;
+        std::vector<RegTab> tabs;
+        std::vector<RegTerm> rterms;
+        std::vector<DevExpr> rexprs;
+        std::vector<DevMat> rmats;
+        std::vector<DevComp> rcomps;
+        std::vector<int32_t> rfacts;
+        std::vector<int32_t> init_mat(n, -1);
+        auto r_expr = [&](int e, double scale, int dst, int gate = 0) {
+            rexprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale, dst, gate});
+        };
+        auto r_matrix = [&](const Item& g) {
+            if (g.gate != QK_UC) {
+                rmats.push_back(DevMat{g.gate, 0});
+                const int mi = (int)rmats.size() - 1;
+                if (g.expr >= 0) r_expr(g.expr, 0.5, ~mi, g.gate);
+                return mi;
+            }
+            DevComp dc{};
+            dc.first = (int)rfacts.size();
+            dc.count = (int)comps[g.expr].size();
+            for (const Factor& f : comps[g.expr]) {
+                rmats.push_back(DevMat{f.gate, 0});
+                const int fi = (int)rmats.size() - 1;
+                if (f.expr >= 0) r_expr(f.expr, f.gate == QK_P ? 1.0 : 0.5, ~fi, f.gate);
+                rfacts.push_back(fi);
+            }
+            rmats.push_back(DevMat{QK_UC, 0});
+            dc.dst = (int)rmats.size() - 1;
+            rcomps.push_back(dc);
+            return dc.dst;
+        };
+        bool all_h = (int)inits.size() == n;
+        for (const Item& g : inits) {
+            init_mat[g.q0] = r_matrix(g);
+            all_h = all_h && g.gate == QK_H;
+        }
+        auto table = [&](const std::vector<int>& bits, size_t from, uint32_t fixed, int t0, int nt) {
+            RegTab t{};
+            t.nbits = (int)std::min<size_t>(4, bits.size() - std::min(from, bits.size()));
+            for (int k = 0; k < t.nbits; ++k) t.bits[k] = bits[from + k];
+            t.fixed = fixed;
+            t.t0 = t0;
+            t.nt = nt;
+            tabs.push_back(t);
+        };
+        for (size_t si = 0; si < sd.size(); ++si) {
+            const SegDraft& g = sd[si];
+            RegSeg sg{};
+            std::vector<int> tb, lo, hi;
+            for (int k = 0; k < RB; ++k) sg.g[k] = g.bits[k];
+            auto rpos = [&](int q) { return (int)(std::find(g.bits.begin(), g.bits.end(), q) - g.bits.begin()); };
+            for (int q = 0; q < n; ++q)
+                if (rpos(q) == RB) tb.push_back(q);
+            {   // deposit runs: thread bit j -> qubit tb[j]; maximal runs with a constant shift
+                sg.nrun = 0;
+                for (size_t j = 0; j < tb.size();) {
+                    const int sh = tb[j] - (int)j;
+                    uint32_t mask = 0;
+                    while (j < tb.size() && tb[j] - (int)j == sh) mask |= 1u << j, ++j;
+                    sg.run[sg.nrun++] = mask | ((uint32_t)sh << 16);
+                }
+            }
+            lo.assign(tb.begin(), tb.begin() + 4);
+            hi.assign(tb.begin() + 4, tb.end());
+            auto in = [](const std::vector<int>& v, int q) { return std::find(v.begin(), v.end(), q) != v.end(); };
+            // three tables (four when the thread has nine bits): register bits, low thread bits, high thread bits
+            // three tables: register bits, low thread bits, high thread bits -- the last one in 2^(extra) slots of 16
+            // entries when the thread has more than eight bits (slot = value of the extra bits, ascending)
+            auto tables = [&](int tA, int nA, int tL, int nL, int tH, int nH) {
+                const int first = (int)tabs.size();
+                table(g.bits, 0, 0u, tA, nA);
+                table(lo, 0, 0u, tL, nL);
+                const int extra = std::max(0, (int)hi.size() - 4);
+                for (int x = 0; x < (1 << extra); ++x) {
+                    uint32_t fixed = 0;
+                    for (int b = 0; b < extra; ++b)
+                        if ((x >> b) & 1) fixed |= 1u << hi[4 + b];
+                    table(hi, 0, fixed, tH, nH);
+                }
+                return first;
+            };
+            uint32_t extra_mask = 0;
+            for (size_t b = 4; b < hi.size(); ++b) extra_mask |= 1u << hi[b];
+            sg.op0 = (int)rops.size();
+            if (si == 0) {
+                RegOp op{};
+                op.kind = RG_INIT;
+                op.flags = all_h ? 1 : 0;
+                op.tab = tables(0, -1, 0, -1, (int)extra_mask, -1);   // nt < 0: first-column products; t0 = mask of the extra qubits (values: fixed)
+                rops.push_back(op);
+            }
+            for (int id : g.ids) {
+                const Proto& p = seq[id];
+                RegOp op{};
+                if (p.diag) {
+                    std::vector<Item> cls[5];     // RR, lo, hi, TX, RT
+                    for (const Item& t : p.terms) {
+                        const bool two = t.q1 >= 0 && (t.kind == TM_CZ || t.kind == TM_ZZP);
+                        const bool r0 = in(g.bits, t.q0), r1 = two && in(g.bits, t.q1);
+                        int k;
+                        if (!two) k = r0 ? 0 : (in(lo, t.q0) ? 1 : 2);
+                        else if (r0 && r1) k = 0;
+                        else if (r0 || r1) k = 4;
+                        else if (in(lo, t.q0) && in(lo, t.q1)) k = 1;
+                        else if (in(hi, t.q0) && in(hi, t.q1)) k = 2;
+                        else k = 3;
+                        cls[k].push_back(t);
+                    }
+                    int start[6];
+                    for (int k = 0; k < 5; ++k) {
+                        start[k] = (int)rterms.size();
+                        for (const Item& t : cls[k]) {
+                            RegTerm rt{};
+                            rt.type = t.kind;
+                            rt.va = t.q0;
+                            rt.vb = t.q1 >= 0 ? t.q1 : 0;
+                            rt.rpos = 0;
+                            if (k == 4) {
+                                rt.rpos = in(g.bits, t.q0) ? rpos(t.q0) : rpos(t.q1);
+                                op.flags |= 1 << rt.rpos;
+                            }
+                            rterms.push_back(rt);
+                            if (t.expr >= 0) r_expr(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, (int)rterms.size() - 1);
+                        }
+                    }
+                    start[5] = (int)rterms.size();
+                    op.kind = RG_DIAG;
+                    op.tab = tables(start[0], start[1] - start[0], start[1], start[2] - start[1], start[2], start[3] - start[2]);
+                    op.t0 = start[3];
+                    op.nTX = start[4] - start[3];
+                    op.nRT = start[5] - start[4];
+                } else if (p.nd.kind == ST_U1) {
+                    // gates on distinct register qubits commute: up to four of them travel as ONE op (one record, the
+                    // matrices read together) -- a layer of Hadamards on the group is a single op without matrices
+                    const int pos = rpos(p.nd.q0), mi = r_matrix(p.nd);
+                    const int gate = p.nd.gate;      // butterfly form: 3 hadamard (adds only), 0 real matrix, 1 rx-shaped, 2 general
+                    const int form = gate == QK_H ? 3 : ((gate == QK_X || gate == QK_RY) ? 0 : (gate == QK_RX ? 1 : 2));
+                    if (!rops.empty() && (int)rops.size() > sg.op0 && rops.back().kind == RG_U1 && !((rops.back().a >> pos) & 1)) {
+                        RegOp& u = rops.back();
+                        u.a |= 1 << pos;
+                        u.b |= mi << (8 * pos);
+                        u.flags |= form << (2 * pos);
+                        continue;
+                    }
+                    op.kind = RG_U1;
+                    op.a = 1 << pos;
+                    op.b = mi << (8 * pos);
+                    op.flags = form << (2 * pos);
+                } else if (p.nd.kind == ST_CX) {
+                    op.b = rpos(p.nd.q1);
+                    if (in(g.bits, p.nd.q0)) { op.kind = RG_CX; op.a = rpos(p.nd.q0); }
+                    else { op.kind = RG_CXT; op.a = (int)(std::find(tb.begin(), tb.end(), p.nd.q0) - tb.begin()); }
+                } else {
+                    op.kind = RG_ECR;
+                    op.a = rpos(p.nd.q0);
+                    op.b = rpos(p.nd.q1);
+                }
+                rops.push_back(op);
+            }
+            sg.op1 = (int)rops.size();
+            segs.push_back(sg);
+        }
+        const bool fits = (int)tabs.size() <= kRegMaxTabs && (int)rterms.size() <= kRegMaxTerms && (int)rmats.size() <= std::min(kRegMaxMats, 255);
+        const size_t lds = ((size_t)16 << n) + 32 * rterms.size() + 64 * rmats.size() + (256 + 32) * tabs.size() + 16 * rcomps.size() +
+                           8 * rexprs.size() + 4 * rfacts.size() + 4 * (size_t)n + 64 +
+                           (size_t)32 * ((rexprs.size() + 63) / 64 * 64);   // two angle buffers, slots of 64 pairs
+        const size_t waves = std::max<size_t>(1, ((size_t)1 << (n - RB)) / 64);
+        const size_t nd = ((rexprs.size() + 63) / 64 + waves - 1) / waves;    // angle fetches per wave and sample: at most 4 (counted waits)
+        if (fits && nd <= 4 && lds <= (size_t)160 * 1024) {
+            // angle programs of one shape side by side (as for the LDS kernel's pre-pass): uniform control flow per wave
+            auto shape = [&](const DevExpr& e) {
+                uint64_t hsh = 1469598103934665603ull;
+                for (int k = 0; k < e.len; ++k) hsh = (hsh ^ (uint64_t)(c.prog[e.start + k].op + 1)) * 1099511628211ull;
+                return hsh ^ (uint64_t)e.len;
+            };
+            std::stable_sort(rexprs.begin(), rexprs.end(), [&](const DevExpr& x, const DevExpr& y) {
+                if (x.len != y.len) return x.len > y.len;
+                return shape(x) < shape(y);
+            });
+            auto pad16 = [](size_t b) { return (b + 15) / 16 * 16; };
+            RegHeader H{};
+            H.L = n;
+            H.n_seg = (int)segs.size(); H.n_op = (int)rops.size(); H.n_tab = (int)tabs.size(); H.n_term = (int)rterms.size();
+            H.n_expr = (int)rexprs.size(); H.n_mat = (int)rmats.size(); H.n_comp = (int)rcomps.size(); H.n_fact = (int)rfacts.size();
+            H.init_h = all_h ? 1 : 0;
+            H.rb = RB;
+            H.init_c = std::ldexp((n & 1) ? 0.70710678118654752440 : 1.0, -(n / 2));
+            size_t off = pad16(sizeof(RegHeader));
+            H.off_seg = (int)off;  off = pad16(off + segs.size() * sizeof(RegSeg));
+            H.off_op = (int)off;   off = pad16(off + rops.size() * sizeof(RegOp));
+            H.off_tab = (int)off;  off = pad16(off + tabs.size() * sizeof(RegTab));
+            H.off_term = (int)off; off = pad16(off + rterms.size() * sizeof(RegTerm));
+            H.off_expr = (int)off; off = pad16(off + rexprs.size() * sizeof(DevExpr));
+            H.off_mat = (int)off;  off = pad16(off + rmats.size() * sizeof(DevMat));
+            H.off_comp = (int)off; off = pad16(off + rcomps.size() * sizeof(DevComp));
+            H.off_fact = (int)off; off = pad16(off + rfacts.size() * sizeof(int32_t));
+            H.off_init = (int)off; off = pad16(off + init_mat.size() * sizeof(int32_t));
+            H.bytes = (int)off;
+            c.reg_blob.assign(off / 8, 0);
+            char* base = (char*)c.reg_blob.data();
+            auto put = [&](int at, const void* src, size_t bytes) { if (bytes) std::memcpy(base + at, src, bytes); };
+            put(0, &H, sizeof(H));
+            put(H.off_seg, segs.data(), segs.size() * sizeof(RegSeg));
+            put(H.off_op, rops.data(), rops.size() * sizeof(RegOp));
+            put(H.off_tab, tabs.data(), tabs.size() * sizeof(RegTab));
+            put(H.off_term, rterms.data(), rterms.size() * sizeof(RegTerm));
+            put(H.off_expr, rexprs.data(), rexprs.size() * sizeof(DevExpr));
+            put(H.off_mat, rmats.data(), rmats.size() * sizeof(DevMat));
+            put(H.off_comp, rcomps.data(), rcomps.size() * sizeof(DevComp));
+            put(H.off_fact, rfacts.data(), rfacts.size() * sizeof(int32_t));
+            put(H.off_init, init_mat.data(), init_mat.size() * sizeof(int32_t));
+            c.reg_lds_bytes = lds;
+            c.plan_summary += "; register-resident plan: " + std::to_string(segs.size()) + " segments, " + std::to_string(rops.size()) +
+                              " ops, " + std::to_string(tabs.size()) + " tables";
+        }
     }
     return QK_OK;
 }

@@ -161,6 +161,7 @@ struct DevTables {
     qk_instr* prog = nullptr;
     double* consts = nullptr;
     void* wave = nullptr;      // the wave-resident program, null when the circuit has none
+    void* reg = nullptr;       // the register-resident program, null when the circuit has none
 };
 }  // namespace qk
 
@@ -182,6 +183,9 @@ struct qk_circuit {
     // wave-resident program (n_qubits <= 10): one position-independent blob, empty when the circuit does not qualify
     std::vector<uint64_t> wave_blob;
     int wave_spw = 1;                // samples per unit of work
+    // register-resident program (10..13 qubits, one pass: qk_reg.h), empty when the circuit does not qualify
+    std::vector<uint64_t> reg_blob;
+    size_t reg_lds_bytes = 0;
     // device copies: one set of tables per device, uploaded on first use there and kept until the circuit is
     // destroyed (under `mu`: ctypes releases the GIL, so two host threads may reach the first call together; a
     // caller works from a by-value copy of its device's pointers, so another thread on another device cannot
@@ -212,6 +216,8 @@ int wave_nreg_class(int n_qubits);
 size_t wave_lds_bytes(const qk_circuit& c);   // the (cos, sin) table of one unit of work
 int launch_wave_jobs(const WaveJob* jobs_host, int n_jobs, const WaveJob* table_dev, int nreg, int64_t total_units,
                      size_t cs_bytes, hipStream_t stream);
+// qk_reg.hip: the register-resident simulator (cs: the (cos, sin) table of the blob's angle programs, [expr][sample])
+int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* psi, void* psi32, hipStream_t stream);
 // qk_sim.hip
 int upload_circuit(qk_circuit& c, DevTables& out);   // the tables of the current device (uploaded on first use)
 void free_circuit_device(qk_circuit& c);

@@ -1,0 +1,72 @@
+// Program format of the register-resident simulator (qk_reg.hip): circuits of 10 to 13 qubits that run as ONE pass
+// with every qubit local.  The 2^L amplitudes of a sample live in the registers of one workgroup, 16 per thread,
+// across all stages; LDS only carries them from one register layout to the next.
+//
+// A layout is a choice of four "register" qubits: a thread's 16 amplitudes differ in exactly those bits, the other
+// L - 4 bits are the thread's index (ascending).  Every non-diagonal gate is applied where its target is a register
+// qubit -- a butterfly between two registers of the lane, no data movement, no index arithmetic -- and diagonal
+// stages are applied in whatever layout the state happens to be in.  The planner (qk_circuit.cpp) cuts the circuit
+// into segments, one layout each; between two segments the workgroup transposes through LDS.
+#pragma once
+#include <cstdint>
+
+namespace qk {
+
+constexpr int kRegMinQubits = 10;     // 64 threads x 16 amplitudes
+constexpr int kRegMaxQubits = 13;     // 512 threads x 16 amplitudes = 128 KiB of LDS for the transposes
+constexpr int kRegMaxTabs = 96;       // phase tables of 16 entries (256 bytes each) per sample
+constexpr int kRegMaxTerms = 256;
+constexpr int kRegMaxMats = 160;
+
+enum RegOpKind : int32_t {
+    RG_INIT = 0,   // the product state of the hoisted first gates (tab: three or four tables of first-column products)
+    RG_DIAG = 1,   // a diagonal stage: tables A (register bits), Blo / Bhi (thread bits), cross terms evaluated per thread
+    RG_U1 = 2,     // 2x2 matrices on the register positions in mask a (distinct positions commute): matrix index of
+                   // position p in byte p of b, butterfly form in bits 2p, 2p + 1 of flags
+    RG_CX = 3,     // control register position a, target register position b
+    RG_CXT = 4,    // control thread bit a (index into the thread's bits), target register position b
+    RG_ECR = 5,    // ecr(q0, q1) on register positions a, b
+};
+
+struct RegOp {        // 32 bytes
+    int32_t kind;
+    int32_t a, b;
+    int32_t tab;      // INIT / DIAG: first table slot: A, Blo, Bhi (two slots when the thread has nine bits)
+    int32_t t0;       // DIAG: first of the terms evaluated per thread: nTX between two thread bits, then nRT between a
+    int32_t nTX, nRT; //       register bit and a thread bit (RegTerm::rpos = that register position)
+    int32_t flags;    // DIAG: bits 0..3 = register positions that have RT terms; INIT: bit 0 = every first gate is a Hadamard;
+                      // U1: butterfly form (0 real matrix, 1 rx-shaped, 2 general, 3 hadamard)
+};
+
+struct RegSeg {       // 64 bytes: one layout and the ops applied in it
+    int32_t g[4];     // the register qubits, ascending
+    int32_t op0, op1;
+    // the thread's part of the amplitude index: its bits dealt to the non-register qubits, ascending, as at most five
+    // runs of consecutive bits:  wt = OR_r ((tid & run_mask[r]) << run_shift[r])
+    int32_t nrun;
+    uint32_t run[5];  // run_mask | run_shift << 16
+    int32_t pad[4];
+};
+
+struct RegTab {       // 32 bytes: one table of 16 entries; entry x covers the index fixed | deposit(x over bits)
+    int32_t bits[4];
+    int32_t nbits;
+    uint32_t fixed;
+    int32_t t0, nt;   // product over terms [t0, t0 + nt); nt < 0: product of the first columns of the qubits in `bits`
+                      // and of the qubits in the mask t0 (whose values `fixed` holds)
+};
+
+struct RegTerm {      // static part of a diagonal term
+    int32_t type;     // TermKind
+    int32_t va, vb;
+    int32_t rpos;     // RT terms: register position of the term's register bit
+};
+
+struct RegHeader {    // at offset 0 of the blob; off_* are byte offsets from its start (16-byte aligned sections)
+    int32_t L, n_seg, n_op, n_tab, n_term, n_expr, n_mat, n_comp, n_fact, init_h;
+    int32_t off_seg, off_op, off_tab, off_term, off_expr, off_mat, off_comp, off_fact, off_init, bytes;
+    int32_t rb, pad;  // register qubits per layout: 4 (16 amplitudes per thread) or 3 (8 per thread, twice the threads)
+    double init_c;    // 2^(-L/2): the product state of an all-Hadamard first layer
+};
+
+}  // namespace qk

@@ -1,0 +1,615 @@
+// Register-resident statevector simulator for gfx950: circuits of 10 to 13 qubits (format and idea: qk_reg.h).
+//
+// One workgroup of 2^(L-4) threads per sample, 16 amplitudes per thread, held in registers across ALL stages of the
+// circuit.  In a layout four qubits are "register" qubits -- a thread's 16 amplitudes differ in exactly those bits --
+// and every gate is applied where its target is a register qubit: a butterfly between registers of the lane, with
+// the matrix in scalar registers.  Diagonal stages are applied in whatever layout the state is in: the phase of
+// amplitude (k, t) is  A[k] * Blo[t & 15] * Bhi[t >> 4] * (the few terms that straddle those three bit groups),
+// three 16-entry tables per stage instead of the LDS kernel's 64 + 64 + 6 x 64 entries with chains of a dozen
+// factors, and the straddling terms cost a thread one ratio per register bit that it walks in Gray-code order.
+// Between two layouts the workgroup transposes through LDS: every thread writes its 16 amplitudes to its OWN slots
+// of the layout it is in, one barrier, and reads the 16 of the next layout -- slots only it will write again, so one
+// barrier per transpose is enough.  The LDS image is XOR-swizzled (slot = i ^ (i >> 4 & 15) ^ (i >> 8 & 15) ^ (i >> 12)):
+// linear over the index bits, so a thread's slot is (its own part) ^ (a scalar per register), and the 8 (writes) or 16
+// (reads) lanes that the LDS serves together hit distinct 16-byte slots whichever aligned group of four is in registers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+
+#include "qk_common.h"
+#include "qk_reg.h"
+
+namespace qk {
+
+typedef double v2d __attribute__((ext_vector_type(2)));   // native vector: stays in registers
+
+struct RegArgs {
+    const char* blob;      // RegHeader + tables (device)
+    const double2* cs;     // (cos, sin) of every angle program, [expr][sample]
+    int64_t N;
+    double2* psi;
+    float2* psi32;         // FP32 output: the state is evolved in FP64 and rounded once, at the store
+    int64_t D;
+    double* trace;         // QK_REG_TRACE builds: 8 doubles per workgroup (100 MHz ticks per phase, summed over its samples)
+};
+
+namespace {
+
+#define QK_CONST_AS __attribute__((address_space(4)))
+typedef const int32_t QK_CONST_AS* CWords;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ CWords cwords(const void* p) { return (CWords)(uintptr_t)p; }
+
+__device__ __forceinline__ v2d cmul(v2d a, v2d b) { return (v2d){fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)}; }
+__device__ __forceinline__ v2d cmulc(v2d a, v2d b) {      // a * conj(b)
+    return (v2d){fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y))};
+}
+__device__ __forceinline__ double2 cmul2(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ double2 cfma2(double2 a, double2 b, double2 c) {
+    return make_double2(fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y)));
+}
+__device__ __forceinline__ double uniform_f64(double x) {
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS accesses of the sample loop go through 32-bit LDS addresses turned into pointers on the spot.  The angles arrive
+// by LDS-DMA, and behind a DMA instruction the compiler puts s_waitcnt vmcnt(0) in front of every LDS access whose
+// pointer it can trace to the workgroup's LDS block -- the very wait (memory operations complete in order: it would
+// also sit out the previous sample's stores) that the counted wait at the top of the sample loop replaces.
+template <class T> __device__ __forceinline__ T ldsr(uint32_t addr) { return *(const __attribute__((address_space(3))) T*)(size_t)addr; }
+template <class T> __device__ __forceinline__ void ldsw(uint32_t addr, T v) { *(__attribute__((address_space(3))) T*)(size_t)addr = v; }
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
+struct TermL { double c, s; int type, va, vb, rpos; };
+__device__ __forceinline__ TermL term_at(uint32_t rt_a, int t) {
+    const v2d cs = ldsr<v2d>(rt_a + 32u * (uint32_t)t);
+    const int4v k = ldsr<int4v>(rt_a + 32u * (uint32_t)t + 16u);
+    return TermL{cs.x, cs.y, k.x, k.y, k.z, k.w};
+}
+__device__ __forceinline__ v2d term_factor(const TermL& t, uint32_t w) {
+    const uint32_t ba = (w >> t.va) & 1u, bb = (w >> t.vb) & 1u;
+    const bool rz = t.type == TM_RZ;
+    const bool on = rz || (t.type == TM_P ? ba != 0u : (t.type == TM_CZ ? (ba & bb) != 0u : (ba ^ bb) != 0u));
+    const double s = (rz && !ba) ? -t.s : t.s;
+    return (v2d){on ? t.c : 1.0, on ? s : 0.0};
+}
+
+__device__ __forceinline__ uint32_t swz(uint32_t i) { return i ^ ((i >> 4) & 15u) ^ ((i >> 8) & 15u) ^ ((i >> 12) & 15u); }
+
+template <int V> struct IC { static constexpr int value = V; };
+template <class F>
+__device__ __forceinline__ void with_pos(int p, F&& f) {      // p is wave-uniform: ONE scalar dispatch, straight-line code behind it
+    if (p == 0) f(IC<0>());
+    else if (p == 1) f(IC<1>());
+    else if (p == 2) f(IC<2>());
+    else f(IC<3>());
+}
+
+// (cos, sin) of one angle into the diagonal term or the 2x2 matrix it feeds (as the LDS kernel's scatter_angle)
+__device__ __forceinline__ void scatter_angle(int dst, int gate, double cn, double sn, uint32_t rt_a, uint32_t mat_a) {
+    if (dst >= 0) {
+        ldsw<v2d>(rt_a + 32u * (uint32_t)dst, (v2d){cn, sn});
+        return;
+    }
+    const uint32_t m = mat_a + 64u * (uint32_t)(~dst);
+    v2d m0, m1, m2, m3;
+    if (gate == QK_RX) { m0 = (v2d){cn, 0}; m1 = (v2d){0, -sn}; m2 = (v2d){0, -sn}; m3 = (v2d){cn, 0}; }
+    else if (gate == QK_RZ) { m0 = (v2d){cn, -sn}; m1 = (v2d){0, 0}; m2 = (v2d){0, 0}; m3 = (v2d){cn, sn}; }
+    else if (gate == QK_P) { m0 = (v2d){1, 0}; m1 = (v2d){0, 0}; m2 = (v2d){0, 0}; m3 = (v2d){cn, sn}; }
+    else { m0 = (v2d){cn, 0}; m1 = (v2d){-sn, 0}; m2 = (v2d){sn, 0}; m3 = (v2d){cn, 0}; }
+    ldsw<v2d>(m, m0); ldsw<v2d>(m + 16u, m1); ldsw<v2d>(m + 32u, m2); ldsw<v2d>(m + 48u, m3);
+}
+
+// a 2x2 matrix on register position P: eight butterflies between registers k and k | (1 << P).  form: 0 real matrix
+// (x, ry), 1 real diagonal + imaginary off-diagonal (rx), 2 general (sx, composites), 3 hadamard (adds only; its
+// 1 / sqrt 2 goes to the running scale).  e0 .. e3: the matrix as it came out of LDS (not read for a hadamard).
+template <int P, int NA>
+__device__ __forceinline__ void u1_reg(v2d (&v)[NA], v2d e0, v2d e1, v2d e2, v2d e3, int form, double& scale) {
+    if constexpr ((1 << P) >= NA) return;
+    if (form == 3) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (!((k >> P) & 1)) {
+                const v2d a0 = v[k], a1 = v[k | (1 << P)];
+                v[k] = a0 + a1;
+                v[k | (1 << P)] = a0 - a1;
+            }
+        scale *= 0.70710678118654752440;
+        return;
+    }
+    const double m0x = uniform_f64(e0.x), m0y = uniform_f64(e0.y), m1x = uniform_f64(e1.x), m1y = uniform_f64(e1.y);
+    const double m2x = uniform_f64(e2.x), m2y = uniform_f64(e2.y), m3x = uniform_f64(e3.x), m3y = uniform_f64(e3.y);
+    if (form == 0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (!((k >> P) & 1)) {
+                const v2d a0 = v[k], a1 = v[k | (1 << P)];
+                v[k] = (v2d){fma(m1x, a1.x, m0x * a0.x), fma(m1x, a1.y, m0x * a0.y)};
+                v[k | (1 << P)] = (v2d){fma(m3x, a1.x, m2x * a0.x), fma(m3x, a1.y, m2x * a0.y)};
+            }
+    } else if (form == 1) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (!((k >> P) & 1)) {
+                const v2d a0 = v[k], a1 = v[k | (1 << P)];
+                v[k] = (v2d){fma(-m1y, a1.y, m0x * a0.x), fma(m1y, a1.x, m0x * a0.y)};
+                v[k | (1 << P)] = (v2d){fma(-m2y, a0.y, m3x * a1.x), fma(m2y, a0.x, m3x * a1.y)};
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (!((k >> P) & 1)) {
+                const v2d a0 = v[k], a1 = v[k | (1 << P)];
+                v[k] = (v2d){fma(m1x, a1.x, fma(-m1y, a1.y, fma(m0x, a0.x, -(m0y * a0.y)))),
+                             fma(m1x, a1.y, fma(m1y, a1.x, fma(m0x, a0.y, m0y * a0.x)))};
+                v[k | (1 << P)] = (v2d){fma(m3x, a1.x, fma(-m3y, a1.y, fma(m2x, a0.x, -(m2y * a0.y)))),
+                                        fma(m3x, a1.y, fma(m3y, a1.x, fma(m2x, a0.y, m2y * a0.x)))};
+            }
+    }
+}
+
+template <int C, int T, int NA>
+__device__ __forceinline__ void cx_reg(v2d (&v)[NA]) {
+    if constexpr (C != T && (1 << C) < NA && (1 << T) < NA) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (((k >> C) & 1) && !((k >> T) & 1)) {
+                const v2d a = v[k];
+                v[k] = v[k | (1 << T)];
+                v[k | (1 << T)] = a;
+            }
+    }
+}
+
+template <int T, int NA>
+__device__ __forceinline__ void cx_thread(v2d (&v)[NA], bool on) {
+    if constexpr ((1 << T) >= NA) return;
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+        if (!((k >> T) & 1)) {
+            const v2d a0 = v[k], a1 = v[k | (1 << T)];
+            v[k] = on ? a1 : a0;
+            v[k | (1 << T)] = on ? a0 : a1;
+        }
+}
+
+// ecr(q0, q1) on register positions P0, P1 (matrix index 2 bit(q1) + bit(q0)); its 1 / sqrt 2 goes to the scale
+template <int P0, int P1, int NA>
+__device__ __forceinline__ void ecr_reg(v2d (&v)[NA]) {
+    if constexpr (P0 != P1 && (1 << P0) < NA && (1 << P1) < NA) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (!((k >> P0) & 1) && !((k >> P1) & 1)) {
+                const v2d p = v[k], q = v[k | (1 << P0)], u = v[k | (1 << P1)], w = v[k | (1 << P0) | (1 << P1)];
+                v[k] = (v2d){q.x - w.y, q.y + w.x};
+                v[k | (1 << P0)] = (v2d){p.x + u.y, p.y - u.x};
+                v[k | (1 << P1)] = (v2d){w.x - q.y, w.y + q.x};
+                v[k | (1 << P0) | (1 << P1)] = (v2d){u.x + p.y, u.y - p.x};
+            }
+    }
+}
+
+}  // namespace
+
+// TBN = log2(threads), RB = register qubits per layout (NA = 2^RB amplitudes per thread), L = TBN + RB.
+// RB = 4: two waves per SIMD (256 VGPRs); RB = 3: four (128 VGPRs) -- LDS holds the same number of samples either way.
+template <int TBN, int RB>
+__global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegArgs a) {
+    extern __shared__ double2 lds[];
+    constexpr int L = TBN + RB, T = 1 << TBN, NA = 1 << RB;
+    const CWords hw = cwords(a.blob);
+    const int n_seg = hw[1], n_tab = hw[3], n_term = hw[4], n_expr = hw[5], n_mat = hw[6], n_comp = hw[7], n_fact = hw[8];
+    const int off_seg = hw[10], off_op = hw[11], off_tab = hw[12], off_term = hw[13], off_expr = hw[14], off_mat = hw[15],
+              off_comp = hw[16], off_fact = hw[17], off_init = hw[18];
+    const double init_c = ((const double*)(a.blob + 88))[0];
+    static_assert(sizeof(RegHeader) == 96 && offsetof(RegHeader, init_c) == 88 && sizeof(RegSeg) == 64, "RegHeader and RegSeg are read word by word");
+    // LDS map (32-bit LDS addresses: see ldsr / ldsw): the transpose image, then per-sample terms, matrices and tables,
+    // then what is staged once per workgroup, then two buffers of angles
+    const uint32_t state_a = (uint32_t)(size_t)(lptr_t)lds;
+    const uint32_t rt_a = state_a + (16u << L);                     // 32 B per term: (cos, sin), type, va, vb, rpos
+    const uint32_t mat_a = rt_a + 32u * (uint32_t)n_term;           // 64 B per matrix
+    const uint32_t tab_a = mat_a + 64u * (uint32_t)n_mat;           // 256 B per table
+    const uint32_t stab_a = tab_a + 256u * (uint32_t)n_tab;         // RegTab records, 32 B
+    const uint32_t comp_a = stab_a + 32u * (uint32_t)n_tab;         // DevComp records, 16 B
+    const uint32_t sexpr_a = comp_a + 16u * (uint32_t)n_comp;       // (dst, gate) of every angle program, 8 B
+    const uint32_t fact_a = sexpr_a + 8u * (uint32_t)n_expr;
+    const uint32_t init_a = fact_a + 4u * (uint32_t)n_fact;
+    const int n_slot = (n_expr + 63) & ~63;                         // one slot of 64 pairs per fetch instruction
+    const uint32_t cs_a = (init_a + 4u * L + 15u) & ~15u;           // two buffers of n_slot (cos, sin) pairs
+    const CWords c_seg = cwords(a.blob + off_seg), c_op = cwords(a.blob + off_op);
+    const int tid0 = threadIdx.x;
+    if (state_a & ((16u << L) - 1u)) __builtin_trap();      // the swizzled image must start where its address bits are clear (dynamic LDS starts at 0)
+
+    // ---- once per workgroup: what does not depend on the sample -----------------------------------------------
+    for (int t = tid0; t < n_term; t += T) {
+        const RegTerm d = ((const RegTerm*)(a.blob + off_term))[t];
+        ldsw<v2d>(rt_a + 32u * t, (v2d){-1.0, 0.0});     // TM_CZ; parametric terms get (cos, sin) per sample
+        ldsw<int4v>(rt_a + 32u * t + 16u, (int4v){d.type, d.va, d.vb, d.rpos});
+    }
+    for (int m = tid0; m < n_mat; m += T) {
+        const int gate = ((const DevMat*)(a.blob + off_mat))[m].gate;
+        const double r = 0.70710678118654752440;
+        v2d m00 = (v2d){0, 0}, m01 = m00, m10 = m00, m11 = m00;
+        if (gate == QK_H) { m00 = (v2d){r, 0}; m01 = (v2d){r, 0}; m10 = (v2d){r, 0}; m11 = (v2d){-r, 0}; }
+        else if (gate == QK_X) { m01 = (v2d){1, 0}; m10 = (v2d){1, 0}; }
+        else if (gate == QK_SX) { m00 = (v2d){0.5, 0.5}; m01 = (v2d){0.5, -0.5}; m10 = (v2d){0.5, -0.5}; m11 = (v2d){0.5, 0.5}; }
+        ldsw<v2d>(mat_a + 64u * m, m00); ldsw<v2d>(mat_a + 64u * m + 16u, m01);
+        ldsw<v2d>(mat_a + 64u * m + 32u, m10); ldsw<v2d>(mat_a + 64u * m + 48u, m11);
+    }
+    for (int t = tid0; t < 8 * n_tab; t += T) ldsw<int>(stab_a + 4u * t, ((const int32_t*)(a.blob + off_tab))[t]);
+    for (int q = tid0; q < L; q += T) ldsw<int>(init_a + 4u * q, ((const int32_t*)(a.blob + off_init))[q]);
+    for (int e = tid0; e < n_expr; e += T) {
+        const DevExpr ex = ((const DevExpr*)(a.blob + off_expr))[e];
+        ldsw<int2v>(sexpr_a + 8u * e, (int2v){ex.dst, ex.gate});
+    }
+    for (int k = tid0; k < 4 * n_comp; k += T) ldsw<int>(comp_a + 4u * k, ((const int32_t*)(a.blob + off_comp))[k]);
+    for (int k = tid0; k < n_fact; k += T) ldsw<int>(fact_a + 4u * k, ((const int32_t*)(a.blob + off_fact))[k]);
+
+    const int64_t per_wg = (a.N + gridDim.x - 1) / gridDim.x;
+    const int64_t s_begin = (int64_t)blockIdx.x * per_wg;
+    const int64_t s_end = s_begin + per_wg < a.N ? s_begin + per_wg : a.N;
+    const int wave_s = uni(tid0 >> 6);
+    // The angles of sample `smp` into buffer `buf`: wave w fetches the slots w, w + T/64, ... (64 angles per DMA
+    // instruction; lanes past the last angle re-read it).  my_nd = how many instructions that is for this wave: the
+    // number of memory operations it has in flight is known where it waits for them.
+    const int my_nd = (n_slot / 64 - wave_s + T / 64 - 1) / (T / 64) > 0 ? (n_slot / 64 - wave_s + T / 64 - 1) / (T / 64) : 0;
+    auto fetch_angles = [&](int64_t smp, int buf, int lane) __attribute__((always_inline)) {
+        for (int j = 0; j < my_nd; ++j) {
+            const int slot = wave_s + j * (T / 64);
+            const int e = min(slot * 64 + lane, n_expr - 1);
+            const double2* src = a.cs + ((int64_t)e * a.N + smp);
+            const uint32_t dst = cs_a + 16u * (uint32_t)(buf * n_slot + slot * 64);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(size_t)dst, 16, 0, 0);
+        }
+    };
+    if (n_expr > 0 && s_begin < s_end) fetch_angles(s_begin, 0, tid0 & 63);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+#ifdef QK_REG_TRACE
+    double tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tr_last = wall_clock64();
+#define QK_RMARK(k) do { if (tid0 == 0) { const uint64_t t_ = wall_clock64(); tr[k] += (double)(t_ - tr_last); tr_last = t_; } } while (0)
+#else
+#define QK_RMARK(k) do { } while (0)
+#endif
+    int it = 0;
+    for (int64_t sample = s_begin; sample < s_end; ++sample, it ^= 1) {
+        // the thread index, rebuilt per sample from an opaque copy (as in sim_pass_kernel: what the compiler can prove
+        // loop-invariant it computes before the loop, keeps across it and spills)
+        uint32_t ones = ~0u;
+        asm volatile("" : "+s"(ones));
+        int tid = (wave_s << 6) | (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        asm volatile("" : "+v"(tid));
+        // The next sample's angles travel while this one is computed.  This sample's were fetched one iteration ago:
+        // younger than them are that iteration's NA stores of Psi and the nd fetches just issued, and memory operations
+        // complete in order -- a counted wait, so the stores go on draining under this sample's arithmetic (a plain
+        // vmcnt(0), which is what a prefetch into registers gets from the compiler, holds the workgroup until the whole
+        // statevector of the previous sample has left the chip).
+        if (my_nd > 0) {
+            fetch_angles(sample + 1 < s_end ? sample + 1 : sample, it ^ 1, tid & 63);
+            if (my_nd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 1) : "memory");
+            else if (my_nd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 2) : "memory");
+            else if (my_nd == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 3) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 4) : "memory");
+        }
+        QK_RMARK(0);
+        lds_barrier();      // every wave's share of this sample's angles has landed; the previous sample is done with terms / matrices / tables
+        QK_RMARK(0);
+        for (int e = tid; e < n_expr; e += T) {
+            const v2d cs = ldsr<v2d>(cs_a + 16u * (uint32_t)(it * n_slot + e));
+            const int2v de = ldsr<int2v>(sexpr_a + 8u * e);
+            scatter_angle(de.x, de.y, cs.x, cs.y, rt_a, mat_a);
+        }
+        lds_barrier();
+        QK_RMARK(0);
+        if (n_comp) {       // runs of single-qubit gates on one qubit: one thread multiplies a run's factors
+            for (int k = tid; k < n_comp; k += T) {
+                const int4v cc = ldsr<int4v>(comp_a + 16u * k);       // dst, first, count
+                auto M = [&](int f, int j) { return ldsr<v2d>(mat_a + 64u * (uint32_t)f + 16u * j); };
+                const int f0 = ldsr<int>(fact_a + 4u * cc.y);
+                v2d m0 = M(f0, 0), m1 = M(f0, 1), m2 = M(f0, 2), m3 = M(f0, 3);
+                for (int j = 1; j < cc.z; ++j) {     // M <- G M
+                    const int f = ldsr<int>(fact_a + 4u * (cc.y + j));
+                    const v2d g0 = M(f, 0), g1 = M(f, 1), g2 = M(f, 2), g3 = M(f, 3);
+                    const v2d n0 = cmul(g0, m0) + cmul(g1, m2), n1 = cmul(g0, m1) + cmul(g1, m3);
+                    const v2d n2 = cmul(g2, m0) + cmul(g3, m2), n3 = cmul(g2, m1) + cmul(g3, m3);
+                    m0 = n0; m1 = n1; m2 = n2; m3 = n3;
+                }
+                const uint32_t d = mat_a + 64u * (uint32_t)cc.x;
+                ldsw<v2d>(d, m0); ldsw<v2d>(d + 16u, m1); ldsw<v2d>(d + 32u, m2); ldsw<v2d>(d + 48u, m3);
+            }
+            lds_barrier();
+        }
+        QK_RMARK(0);
+        // ---- the phase tables of every diagonal stage (and of the product state), 16 entries each ---------------
+        for (int e = tid; e < 16 * n_tab; e += T) {
+            const uint32_t tb = stab_a + 32u * (uint32_t)(e >> 4);      // bits[4], nbits, fixed, t0, nt
+            const int4v bits = ldsr<int4v>(tb), rest = ldsr<int4v>(tb + 16u);
+            const int nbits = rest.x, t0 = rest.z, nt = rest.w;
+            const uint32_t x = (uint32_t)e & 15u;
+            const uint32_t w = (uint32_t)rest.y | ((x & 1u) << bits.x) | (((x >> 1) & 1u) << bits.y) | (((x >> 2) & 1u) << bits.z) |
+                               (((x >> 3) & 1u) << bits.w);       // (unused positions of `bits` are 0 and x stays below 2^nbits where it counts)
+            v2d f = (v2d){1.0, 0.0};
+            if (nt >= 0) {
+                // four terms per step, two chains: their LDS reads are in flight together
+                v2d f2 = (v2d){1.0, 0.0};
+                int k = 0;
+                for (; k + 3 < nt; k += 4) {
+                    const TermL ta = term_at(rt_a, t0 + k), tb2 = term_at(rt_a, t0 + k + 1), tc = term_at(rt_a, t0 + k + 2), td = term_at(rt_a, t0 + k + 3);
+                    f = cmul(f, term_factor(ta, w));
+                    f2 = cmul(f2, term_factor(tb2, w));
+                    f = cmul(f, term_factor(tc, w));
+                    f2 = cmul(f2, term_factor(td, w));
+                }
+                for (; k < nt; ++k) f = cmul(f, term_factor(term_at(rt_a, t0 + k), w));
+                f = cmul(f, f2);
+            } else {
+                auto column = [&](int q, uint32_t bit) {
+                    const int m = ldsr<int>(init_a + 4u * q);
+                    const v2d u = ldsr<v2d>(mat_a + 64u * (uint32_t)(m < 0 ? 0 : m) + 32u * bit);
+                    return m < 0 ? (v2d){bit ? 0.0 : 1.0, 0.0} : u;
+                };
+                if (nbits > 0) f = cmul(f, column(bits.x, x & 1u));
+                if (nbits > 1) f = cmul(f, column(bits.y, (x >> 1) & 1u));
+                if (nbits > 2) f = cmul(f, column(bits.z, (x >> 2) & 1u));
+                if (nbits > 3) f = cmul(f, column(bits.w, (x >> 3) & 1u));
+                for (uint32_t m = (uint32_t)t0; m; m &= m - 1u) {      // the extra high thread qubits of this slot (their values: fixed)
+                    const int q = __builtin_ctz(m);
+                    f = cmul(f, column(q, ((uint32_t)rest.y >> q) & 1u));
+                }
+            }
+            if ((int)x >= (1 << nbits)) f = (v2d){1.0, 0.0};
+            ldsw<v2d>(tab_a + 16u * e, f);
+        }
+        lds_barrier();
+        QK_RMARK(0);
+
+        v2d v[NA];
+        double scale = 1.0;
+        for (int sg = 0; sg < n_seg; ++sg) {
+            // the segment record: 16 words, one scalar load
+            const CWords sr = c_seg + 16 * sg;
+            const int g0 = sr[0], g1 = sr[1], g2 = sr[2], g3 = RB > 3 ? sr[3] : 0;
+            const int op0 = sr[4], op1 = sr[5], nrun = sr[6];
+            // the thread's part of the amplitude index (runs of consecutive bits, set up by the planner)
+            auto run = [&](int r) { const uint32_t w = (uint32_t)sr[7 + r]; return ((uint32_t)tid & (w & 0xffffu)) << (w >> 16); };
+            uint32_t wt = run(0);
+            if (nrun > 1) wt |= run(1);
+            if (nrun > 2) wt |= run(2);
+            if (nrun > 3) wt |= run(3);
+            if (nrun > 4) wt |= run(4);
+            const uint32_t st16 = state_a | (swz(wt) << 4);      // (state_a has none of the image's address bits: checked at the top)
+            // register k's part of the index and of the swizzled LDS address: both are XOR-linear over the register
+            // bits, so four scalars per segment (not a swizzle per register and access) make all sixteen
+            const uint32_t gb0 = 1u << g0, gb1 = 1u << g1, gb2 = 1u << g2, gb3 = RB > 3 ? 1u << g3 : 0u;
+            const uint32_t sb0 = swz(gb0) << 4, sb1 = swz(gb1) << 4, sb2 = swz(gb2) << 4, sb3 = RB > 3 ? swz(gb3) << 4 : 0u;
+            auto kdep = [&](int k) { return ((k & 1) ? gb0 : 0u) | ((k & 2) ? gb1 : 0u) | ((k & 4) ? gb2 : 0u) | ((k & 8) ? gb3 : 0u); };
+            auto kswz = [&](int k) { return ((k & 1) ? sb0 : 0u) ^ ((k & 2) ? sb1 : 0u) ^ ((k & 4) ? sb2 : 0u) ^ ((k & 8) ? sb3 : 0u); };
+            QK_RMARK(1);
+            if (sg > 0) {
+                lds_barrier();      // every thread has written its amplitudes in the previous layout
+#pragma unroll
+                for (int k = 0; k < NA; ++k) v[k] = ldsr<v2d>(st16 ^ kswz(k));
+            }
+            QK_RMARK(2);
+            // An op record is 8 words: one scalar load, issued one op ahead -- read field by field where it is needed,
+            // every op paid two or three scalar-load latencies in a row (each behind an lgkmcnt(0) that also waits
+            // for the LDS traffic in flight).
+            int r_kind = c_op[8 * op0], r_a = c_op[8 * op0 + 1], r_b = c_op[8 * op0 + 2], r_tab = c_op[8 * op0 + 3],
+                r_t0 = c_op[8 * op0 + 4], r_ntx = c_op[8 * op0 + 5], r_nrt = c_op[8 * op0 + 6], r_flags = c_op[8 * op0 + 7];
+            for (int oi = op0; oi < op1; ++oi) {
+                const int kind = r_kind, oa = r_a, ob = r_b, o_tab = r_tab, o_t0 = r_t0, o_ntx = r_ntx, o_nrt = r_nrt, o_flags = r_flags;
+                {
+                    const int nx = 8 * (oi + 1 < op1 ? oi + 1 : oi);
+                    r_kind = c_op[nx]; r_a = c_op[nx + 1]; r_b = c_op[nx + 2]; r_tab = c_op[nx + 3];
+                    r_t0 = c_op[nx + 4]; r_ntx = c_op[nx + 5]; r_nrt = c_op[nx + 6]; r_flags = c_op[nx + 7];
+                }
+                if (kind == RG_U1) {
+                    if (oa == NA - 1 && o_flags == (RB == 4 ? 0xff : 0x3f)) {      // a Hadamard on every register qubit: no matrices
+#pragma unroll
+                        for (int p = 0; p < RB; ++p)
+#pragma unroll
+                            for (int k = 0; k < NA; ++k)
+                                if (!((k >> p) & 1)) {
+                                    const v2d a0 = v[k], a1 = v[k | (1 << p)];
+                                    v[k] = a0 + a1;
+                                    v[k | (1 << p)] = a0 - a1;
+                                }
+                        scale *= RB == 4 ? 0.25 : 0.35355339059327376220;
+                    } else {
+                        // the matrix of the next position is read while the butterflies of the current one run
+                        auto mload = [&](int p, v2d (&m)[4]) __attribute__((always_inline)) {
+                            const uint32_t ma = mat_a + 64u * (uint32_t)((ob >> (8 * p)) & 255);
+                            const bool need = ((oa >> p) & 1) && ((o_flags >> (2 * p)) & 3) != 3;      // wave-uniform
+                            if (need) { m[0] = ldsr<v2d>(ma); m[1] = ldsr<v2d>(ma + 16u); m[2] = ldsr<v2d>(ma + 32u); m[3] = ldsr<v2d>(ma + 48u); }
+                            else { m[0] = m[1] = m[2] = m[3] = (v2d){0.0, 0.0}; }
+                        };
+                        if constexpr (RB > 3) {
+                            v2d ma[4], mb[4];
+                            mload(0, ma);
+                            mload(1, mb);
+                            if (oa & 1) u1_reg<0, NA>(v, ma[0], ma[1], ma[2], ma[3], o_flags & 3, scale);
+                            mload(2, ma);
+                            if (oa & 2) u1_reg<1, NA>(v, mb[0], mb[1], mb[2], mb[3], (o_flags >> 2) & 3, scale);
+                            mload(3, mb);
+                            if (oa & 4) u1_reg<2, NA>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 4) & 3, scale);
+                            if (oa & 8) u1_reg<3, NA>(v, mb[0], mb[1], mb[2], mb[3], (o_flags >> 6) & 3, scale);
+                        } else {      // 128 registers: one matrix at a time
+                            v2d ma[4];
+                            if (oa & 1) { mload(0, ma); u1_reg<0, NA>(v, ma[0], ma[1], ma[2], ma[3], o_flags & 3, scale); }
+                            if (oa & 2) { mload(1, ma); u1_reg<1, NA>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 2) & 3, scale); }
+                            if (oa & 4) { mload(2, ma); u1_reg<2, NA>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 4) & 3, scale); }
+                        }
+                    }
+                } else if (kind == RG_DIAG || kind == RG_INIT) {
+                    const int tb0 = o_tab;
+                    const uint32_t tlo = (uint32_t)tid & 15u, thi = (uint32_t)tid >> 4;
+                    const uint32_t ta = tab_a + 256u * (uint32_t)tb0;      // table A: the register bits
+                    v2d bt = cmul(ldsr<v2d>(ta + 256u + 16u * tlo), ldsr<v2d>(ta + 512u + 16u * thi));   // (thi >= 16: the second Bhi slot follows the first)
+                    if (kind == RG_INIT) {
+                        const int all_h = o_flags & 1;
+                        if (all_h) {
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) v[k] = (v2d){1.0, 0.0};
+                            scale = init_c;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) v[k] = cmul(bt, ldsr<v2d>(ta + 16u * k));
+                        }
+                    } else {
+                        const int t0 = o_t0, nTX = o_ntx, nRT = o_nrt, rtmask = o_flags;
+                        bt = (v2d){bt.x * scale, bt.y * scale};
+                        scale = 1.0;
+                        for (int k = 0; k < nTX; ++k) bt = cmul(bt, term_factor(term_at(rt_a, t0 + k), wt));
+                        v2d r0 = (v2d){1.0, 0.0}, r1 = r0, r2 = r0, r3 = r0;
+                        for (int k = 0; k < nRT; ++k) {
+                            const TermL t = term_at(rt_a, t0 + nTX + k);
+                            const int rp = uni(t.rpos);
+                            const uint32_t gb = rp == 0 ? 1u << g0 : (rp == 1 ? 1u << g1 : (rp == 2 ? 1u << g2 : 1u << g3));
+                            const v2d f0 = term_factor(t, wt), f1 = term_factor(t, wt | gb);
+                            bt = cmul(bt, f0);
+                            const v2d q = cmulc(f1, f0);      // unit modulus: f1 / f0
+                            if (rp == 0) r0 = cmul(r0, q);
+                            else if (rp == 1) r1 = cmul(r1, q);
+                            else if (rp == 2) r2 = cmul(r2, q);
+                            else r3 = cmul(r3, q);
+                        }
+                        if (rtmask == 0) {
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) v[k] = cmul(v[k], cmul(bt, ldsr<v2d>(ta + 16u * k)));
+                        } else {
+                            // Gray-code walk over the register bits: one multiplication by a ratio (or its conjugate) per step
+                            v2d X = bt;
+#pragma unroll
+                            for (int i = 0; i < NA; ++i) {
+                                const int g = i ^ (i >> 1);
+                                if (i > 0) {
+                                    const int b = __builtin_ctz(i);
+                                    if ((rtmask >> b) & 1) {
+                                        const v2d q = b == 0 ? r0 : (b == 1 ? r1 : (b == 2 ? r2 : r3));
+                                        X = ((g >> b) & 1) ? cmul(X, q) : cmulc(X, q);
+                                    }
+                                }
+                                v[g] = cmul(v[g], cmul(X, ldsr<v2d>(ta + 16u * g)));
+                            }
+                        }
+                    }
+                } else if (kind == RG_CX) {
+                    with_pos(oa, [&](auto CC) __attribute__((always_inline)) {
+                        with_pos(ob, [&](auto TT) __attribute__((always_inline)) { cx_reg<decltype(CC)::value, decltype(TT)::value, NA>(v); });
+                    });
+                } else if (kind == RG_CXT) {
+                    const bool on = (((uint32_t)tid >> oa) & 1u) != 0u;
+                    with_pos(ob, [&](auto TT) __attribute__((always_inline)) { cx_thread<decltype(TT)::value, NA>(v, on); });
+                } else {      // RG_ECR
+                    with_pos(oa, [&](auto P0) __attribute__((always_inline)) {
+                        with_pos(ob, [&](auto P1) __attribute__((always_inline)) { ecr_reg<decltype(P0)::value, decltype(P1)::value, NA>(v); });
+                    });
+                    scale *= 0.70710678118654752440;
+                }
+#ifdef QK_REG_TRACE
+                if (kind == RG_DIAG || kind == RG_INIT) QK_RMARK(3); else if (kind == RG_U1) QK_RMARK(4); else QK_RMARK(5);
+#endif
+            }
+            if (sg + 1 < n_seg) {
+                // to the thread's own slots of this layout (the next layout's reads follow the barrier at the top)
+#pragma unroll
+                for (int k = 0; k < NA; ++k) ldsw<v2d>(st16 ^ kswz(k), v[k]);
+                QK_RMARK(6);
+            } else {
+                if (scale != 1.0) {
+#pragma unroll
+                    for (int k = 0; k < NA; ++k) v[k] = (v2d){v[k].x * scale, v[k].y * scale};
+                }
+                // a wave-uniform base per register (scalar registers) plus ONE 32-bit lane offset
+                if (a.psi32) {
+                    char* gp = (char*)(a.psi32 + sample * a.D);
+                    uint32_t off = wt << 3;
+#pragma unroll
+                    for (int k = 0; k < NA; ++k) {
+                        asm volatile("" : "+v"(off));      // keeps zext(off) at the store: selects the SGPR-base form
+                        *(float2*)(gp + ((uint64_t)kdep(k) << 3) + (uint64_t)off) = make_float2((float)v[k].x, (float)v[k].y);
+                    }
+                } else {
+                    char* gp = (char*)(a.psi + sample * a.D);
+                    uint32_t off = wt << 4;
+#pragma unroll
+                    for (int k = 0; k < NA; ++k) {
+                        asm volatile("" : "+v"(off));
+                        *(v2d*)(gp + ((uint64_t)kdep(k) << 4) + (uint64_t)off) = v[k];
+                    }
+                }
+                QK_RMARK(6);
+            }
+        }
+    }
+#ifdef QK_REG_TRACE
+    if (tid0 == 0 && a.trace)
+        for (int k = 0; k < 8; ++k) a.trace[(int64_t)blockIdx.x * 8 + k] = k < 7 ? tr[k] : (double)(s_end - s_begin);
+#endif
+}
+
+int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* psi, void* psi32, hipStream_t stream) {
+    const int L = c.n_qubits;
+    const RegHeader* H = (const RegHeader*)c.reg_blob.data();
+    const int RB = H->rb;
+    const void* fns[2][4] = {{(const void*)reg_sim_kernel<7, 3>, (const void*)reg_sim_kernel<8, 3>, (const void*)reg_sim_kernel<9, 3>, (const void*)reg_sim_kernel<10, 3>},
+                             {(const void*)reg_sim_kernel<6, 4>, (const void*)reg_sim_kernel<7, 4>, (const void*)reg_sim_kernel<8, 4>, (const void*)reg_sim_kernel<9, 4>}};
+    static DeviceOnce attr_set;
+    if (attr_set.pending()) {
+        for (int r = 0; r < 2; ++r)
+            for (int k = 0; k < 4; ++k) QK_HIP(hipFuncSetAttribute(fns[r][k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set.done();
+    }
+    RegArgs a{};
+    a.blob = (const char*)blob_dev;
+    a.cs = cs;
+    a.N = N;
+    a.psi = (double2*)psi;
+    a.psi32 = (float2*)psi32;
+    a.D = (int64_t)1 << L;
+#ifdef QK_REG_TRACE
+    static double* trace_buf = nullptr;
+    if (!trace_buf) QK_HIP(hipMalloc((void**)&trace_buf, 8 * sizeof(double) * 256 * 16));
+    QK_HIP(hipMemsetAsync(trace_buf, 0, 8 * sizeof(double) * 256 * 16, stream));
+    a.trace = trace_buf;
+#endif
+    const size_t lds = c.reg_lds_bytes;
+    const int threads = 1 << (L - RB);
+    // resident workgroups per CU: LDS, and registers (RB = 4: 256 VGPRs, 8 waves per CU; RB = 3: 128 VGPRs, 16 waves)
+    int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)std::max(1, (RB == 3 ? 1024 : 512) / threads));
+    per_cu = std::max(1, per_cu);
+    const int64_t nblocks = std::min<int64_t>(N, (int64_t)256 * per_cu);
+    const dim3 grid((unsigned)nblocks), block(threads);
+    void* args[] = {&a};
+    QK_HIP(hipLaunchKernel(fns[RB == 3 ? 0 : 1][L - 10], grid, block, args, lds, stream));
+    QK_HIP(hipGetLastError());
+#ifdef QK_REG_TRACE
+    {
+        QK_HIP(hipStreamSynchronize(stream));
+        std::vector<double> h(8 * (size_t)nblocks);
+        QK_HIP(hipMemcpy(h.data(), trace_buf, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int64_t b = 0; b < nblocks; ++b)
+            for (int k = 0; k < 8; ++k) sum[k] += h[8 * b + k];
+        std::fprintf(stderr, "[reg trace] L=%d RB=%d blocks=%lld samples=%.0f us per sample and workgroup:", L, RB, (long long)nblocks, sum[7]);
+        const char* names[7] = {"before segments", "segment setup", "transpose read", "init/diag ops", "u1 ops", "other ops", "transpose write / stores"};
+        for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %s %.2f", names[k], sum[k] / sum[7] * 0.01);
+        std::fprintf(stderr, "\n");
+    }
+#endif
+    return QK_OK;
+}
+
+}  // namespace qk

@@ -20,6 +20,7 @@
 #include "qk_common.h"
 #include "qk_math.h"
 #include "qk_rdm.h"
+#include "qk_reg.h"
 #include "qk_wave.h"
 
 namespace qk {
@@ -1178,7 +1179,11 @@ int upload_circuit(qk_circuit& c, DevTables& out) {
         if ((e = up(t.consts, c.consts)) != hipSuccess) return e;
         if (!c.wave_blob.empty()) {
             if ((e = hipMalloc(&t.wave, c.wave_blob.size() * 8)) != hipSuccess) return e;
-            e = hipMemcpy(t.wave, c.wave_blob.data(), c.wave_blob.size() * 8, hipMemcpyHostToDevice);
+            if ((e = hipMemcpy(t.wave, c.wave_blob.data(), c.wave_blob.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        }
+        if (!c.reg_blob.empty()) {
+            if ((e = hipMalloc(&t.reg, c.reg_blob.size() * 8)) != hipSuccess) return e;
+            e = hipMemcpy(t.reg, c.reg_blob.data(), c.reg_blob.size() * 8, hipMemcpyHostToDevice);
         }
         return e;
     };
@@ -1187,6 +1192,7 @@ int upload_circuit(qk_circuit& c, DevTables& out) {
         (void)hipFree(t.stages); (void)hipFree(t.terms); (void)hipFree(t.exprs); (void)hipFree(t.mats);
         (void)hipFree(t.comps); (void)hipFree(t.facts); (void)hipFree(t.prog); (void)hipFree(t.consts);
         if (t.wave) (void)hipFree(t.wave);
+        if (t.reg) (void)hipFree(t.reg);
         return fail(QK_ERR_HIP, std::string("uploading the circuit tables: ") + hipGetErrorString(e));
     }
     c.tables[dev] = t;
@@ -1201,6 +1207,7 @@ void free_circuit_device(qk_circuit& c) {
         (void)hipFree(t.stages); (void)hipFree(t.terms); (void)hipFree(t.exprs); (void)hipFree(t.mats);
         (void)hipFree(t.comps); (void)hipFree(t.facts); (void)hipFree(t.prog); (void)hipFree(t.consts);
         if (t.wave) (void)hipFree(t.wave);
+        if (t.reg) (void)hipFree(t.reg);
     }
     c.tables.clear();
 }
@@ -1266,6 +1273,28 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     const bool big = (N >> 22 >> 0) != 0 || (N << n) >= ((int64_t)1 << 22);
     const bool prefer_lds = !force_wave && (big || n > kWaveMaxQubits) && ((direct_shape && (n >= 9 || (n >= 6 && all_h_init(c.passes[0])))) ||
                                             (n >= 6 && h_layers_shape()));
+    // 10 to 13 qubits in one pass with butterflies or swaps to do: the register-resident kernel (qk_reg.hip).  A circuit
+    // that is the product state and ONE diagonal stage stays on the direct-store pass below (nothing to keep in
+    // registers: it writes every amplitude once).  QK_SIM_PATH=reg sends every circuit that has such a plan there,
+    // QK_SIM_PATH=noreg none (A/B runs).
+    static const int reg_mode = [] {
+        const char* e = std::getenv("QK_SIM_PATH");
+        return !e ? 0 : (std::strcmp(e, "reg") == 0 ? 1 : (std::strcmp(e, "noreg") == 0 || std::strcmp(e, "lds") == 0 || std::strcmp(e, "wave") == 0 ? -1 : 0));
+    }();
+    if (dt.reg && !rdm_dev && reg_mode >= 0 && (reg_mode > 0 || (!direct_shape && n >= 11))) {
+        const RegHeader* H = (const RegHeader*)c.reg_blob.data();
+        double2* cs = nullptr;
+        if (H->n_expr > 0) {
+            if ((N + 63) / 64 > 0x7fffffff) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
+            QK_HIP(hipMallocAsync((void**)&cs, (size_t)H->n_expr * (size_t)N * sizeof(double2), (hipStream_t)stream));
+            hipLaunchKernelGGL(angle_table_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((H->n_expr + 3) / 4)), dim3(256), 0,
+                               (hipStream_t)stream, (const DevExpr*)((const char*)dt.reg + H->off_expr), H->n_expr, dt.prog, dt.consts,
+                               X_dev, ldx, N, cs);
+        }
+        rc = launch_reg_sim(c, dt.reg, cs, N, psi32_dev ? nullptr : psi_dev, psi32_dev, (hipStream_t)stream);
+        if (cs) (void)hipFreeAsync(cs, (hipStream_t)stream);
+        return rc;
+    }
     if (dt.wave && !rdm_dev && !force_lds && !prefer_lds) {
         WaveJob job{};
         job.prog = dt.wave;
