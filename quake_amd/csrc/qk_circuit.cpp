@@ -608,8 +608,10 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         }
         // register qubits per layout: 3 = 8 amplitudes per thread and twice the threads (twice the waves per CU for the
         // same LDS: the kernel is bound by latency, not by issue); QK_REG_RB overrides (A/B runs)
+        // (QK_REG_RB=3 selects the 8-amplitude form for A/B runs; it is not the default: at 128 registers the compiler
+        // still spills a few values, and a scratch access would break the kernel's counted memory waits)
         static const int rb_env = std::getenv("QK_REG_RB") ? std::atoi(std::getenv("QK_REG_RB")) : 0;
-        const int RB = (rb_env == 3 || rb_env == 4) ? rb_env : 4;
+        const int RB = rb_env == 3 ? 3 : 4;
         struct SegDraft { std::vector<int> bits, ids; };
         std::vector<SegDraft> sd(1);
         for (int id : order) {
@@ -764,6 +766,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                     }
                     start[5] = (int)rterms.size();
                     op.kind = RG_DIAG;
+                    // directly behind the product state of an all-Hadamard first layer every amplitude is still the constant
+                    // held in the running scale: the stage writes its phases instead of multiplying by them
+                    if (!rops.empty() && (int)rops.size() == sg.op0 + 1 && rops.back().kind == RG_INIT && (rops.back().flags & 1)) op.flags |= 256;
                     op.tab = tables(start[0], start[1] - start[0], start[1], start[2] - start[1], start[2], start[3] - start[2]);
                     op.t0 = start[3];
                     op.nTX = start[4] - start[3];

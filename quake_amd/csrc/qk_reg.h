@@ -34,7 +34,7 @@ struct RegOp {        // 32 bytes
     int32_t tab;      // INIT / DIAG: first table slot: A, Blo, Bhi (two slots when the thread has nine bits)
     int32_t t0;       // DIAG: first of the terms evaluated per thread: nTX between two thread bits, then nRT between a
     int32_t nTX, nRT; //       register bit and a thread bit (RegTerm::rpos = that register position)
-    int32_t flags;    // DIAG: bits 0..3 = register positions that have RT terms; INIT: bit 0 = every first gate is a Hadamard;
+    int32_t flags;    // DIAG: bits 0..3 = register positions that have RT terms, bit 8 = the state is still the identity; INIT: bit 0 = every first gate is a Hadamard;
                       // U1: butterfly form (0 real matrix, 1 rx-shaped, 2 general, 3 hadamard)
 };
 

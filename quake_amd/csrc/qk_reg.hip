@@ -468,7 +468,8 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                             for (int k = 0; k < NA; ++k) v[k] = cmul(bt, ldsr<v2d>(ta + 16u * k));
                         }
                     } else {
-                        const int t0 = o_t0, nTX = o_ntx, nRT = o_nrt, rtmask = o_flags;
+                        const int t0 = o_t0, nTX = o_ntx, nRT = o_nrt, rtmask = o_flags & 15;
+                        const bool fresh = (o_flags & 256) != 0;      // the state is the identity times the running scale: write, do not multiply
                         bt = (v2d){bt.x * scale, bt.y * scale};
                         scale = 1.0;
                         for (int k = 0; k < nTX; ++k) bt = cmul(bt, term_factor(term_at(rt_a, t0 + k), wt));
@@ -487,7 +488,10 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                         }
                         if (rtmask == 0) {
 #pragma unroll
-                            for (int k = 0; k < NA; ++k) v[k] = cmul(v[k], cmul(bt, ldsr<v2d>(ta + 16u * k)));
+                            for (int k = 0; k < NA; ++k) {
+                                const v2d ph = cmul(bt, ldsr<v2d>(ta + 16u * k));
+                                v[k] = fresh ? ph : cmul(v[k], ph);
+                            }
                         } else {
                             // Gray-code walk over the register bits: one multiplication by a ratio (or its conjugate) per step
                             v2d X = bt;
@@ -501,7 +505,8 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                                         X = ((g >> b) & 1) ? cmul(X, q) : cmulc(X, q);
                                     }
                                 }
-                                v[g] = cmul(v[g], cmul(X, ldsr<v2d>(ta + 16u * g)));
+                                const v2d ph = cmul(X, ldsr<v2d>(ta + 16u * g));
+                                v[g] = fresh ? ph : cmul(v[g], ph);
                             }
                         }
                     }

@@ -184,7 +184,7 @@ def test_statevectors_fresh_high_qubits(n):
     assert np.abs(got - psi_from_compiled(circ, X)).max() < TOL_PSI
 
 
-@pytest.mark.parametrize("n,seed", [(11, 0), (14, 1), (15, 2), (16, 3)])
+@pytest.mark.parametrize("n,seed", [(11, 0), (12, 4), (13, 5), (14, 1), (15, 2), (16, 3)])
 def test_statevectors_random_circuits(n, seed):
     """Random gate soups: every stage kind, many cross-half diagonal terms, several passes."""
     rng = np.random.default_rng(seed)
@@ -209,6 +209,55 @@ def test_statevectors_random_circuits(n, seed):
     X = synth_X(2, 5, "scaled", 400 + n)
     got = HipFidelityKernel(c).statevectors(X)
     assert np.abs(got - psi_from_compiled(c, X)).max() < TOL_PSI
+
+
+def _gate_soup(n, seed, gates, F=5):
+    rng = np.random.default_rng(seed)
+    x = qc.ParameterVector("x", F)
+    c = qc.QuantumCircuit(n)
+    for k in range(F):
+        c.ry(x[k] * 0.7, int(rng.integers(0, n)))
+    for _ in range(gates):
+        g = rng.integers(0, 11)
+        q, r = (int(v) for v in rng.choice(n, size=2, replace=False))
+        a = x[int(rng.integers(0, F))] * float(rng.uniform(0.5, 2.0))
+        if g == 0: c.h(q)
+        elif g == 1: c.sx(q)
+        elif g == 2: c.x(q)
+        elif g == 3: c.rx(a, q)
+        elif g == 4: c.ry(a, q)
+        elif g == 5: c.rz(a, q)
+        elif g == 6: c.p(a, q)
+        elif g == 7: c.cx(q, r)
+        elif g == 8: c.cz(q, r)
+        elif g == 9: c.ecr(q, r)
+        else:
+            c.cx(q, r); c.p(a, r); c.cx(q, r)
+    return c
+
+
+@pytest.mark.parametrize("n,seed,N", [(11, 20, 1500), (12, 21, 1100), (13, 22, 600)])
+def test_register_resident_simulator_many_samples(n, seed, N):
+    """The register-resident kernel (qk_reg.hip: 11-13 qubits, one pass) on gate soups -- register-register and
+    thread-controlled cx, ecr, composite matrices, diagonal stages with terms between register and thread bits in
+    every layout -- with several samples per persistent workgroup (angle double buffer, counted memory waits) and in
+    the FP32-output mode; rows sampled against the oracle's simulator, every row's norm checked."""
+    import torch
+    from quake_amd import device as qdev
+    c = _gate_soup(n, seed, 9 * n)
+    h = HipFidelityKernel(c)._circuit()
+    assert h.num_passes == 1 and "register-resident plan" in h.plan_summary
+    X = synth_X(N, 5, "scaled", 700 + n)
+    dc = qdev.DeviceCircuit(c)
+    Xd = torch.from_numpy(X).cuda()
+    psi = dc.simulate(Xd)
+    rows = np.unique(np.concatenate([[0, 1, N // 2, N - 2, N - 1], np.random.default_rng(n).integers(0, N, 7)]))
+    ref = psi_from_compiled(c, X[rows])
+    assert np.abs(psi[torch.from_numpy(rows).cuda()].cpu().numpy() - ref).max() < TOL_PSI
+    assert float(((psi.real ** 2 + psi.imag ** 2).sum(dim=1) - 1.0).abs().max()) < 1e-12
+    psi32 = dc.simulate(Xd, dtype=torch.complex64)
+    assert np.abs(psi32[torch.from_numpy(rows).cuda()].cpu().numpy() - ref).max() < 2e-7
+    del psi, psi32
 
 
 @pytest.mark.parametrize("n,seed", [(1, 0), (3, 1), (7, 2), (10, 3), (11, 4), (12, 5), (14, 6)])
