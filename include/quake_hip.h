@@ -240,6 +240,9 @@ int qk_kernel_stats_dev(const double* K_dev, int64_t N, int64_t ldk, const int32
  * workspace.  Calls no hipMalloc / hipFree.  N above QK_STATS_NOALLOC_MAX_N is refused
  * (QK_ERR_UNSUPPORTED).  All calls on one GPU share that array: calls that overlap on one GPU (two
  * streams, two threads) race -- serialise them, or use qk_kernel_stats_dev with a workspace per stream.
+ * The GPU that K lives on must be the current device (QK_ERR_INVALID otherwise: each GPU has its own copy of
+ * the array).  The first call on a device looks the array's address up (hipGetSymbolAddress): make that call
+ * outside stream capture, e.g. once at start-up; later calls only launch kernels.
  */
 #define QK_STATS_NOALLOC_MAX_N 131072
 int qk_kernel_stats_noalloc_dev(const double* K_dev, int64_t N, int64_t ldk, const int32_t* labels_dev,
@@ -260,6 +263,19 @@ int qk_kernel_stats_noalloc_dev(const double* K_dev, int64_t N, int64_t ldk, con
 #define QK_NOISE_SHOTS 2
 int qk_kernel_noise_dev(double* K_dev, int64_t N, int64_t ldk, int mode, double param, uint64_t seed,
                         void* stream);
+/* The same models on a rectangular rows x cols block (a test-versus-train kernel: every entry drawn,
+ * no mirror), entry (i, j) keyed by (i, j) as above. */
+int qk_kernel_noise_rect_dev(double* K_dev, int64_t rows, int64_t cols, int64_t ldk, int mode, double param,
+                             uint64_t seed, void* stream);
+/*
+ * Replaces: kernel.evaluate(x_vec, y_vec=None) of FidelityStatevectorKernel(shots=...) (the finite-shot
+ * kernel qiskit-machine-learning samples from the exact fidelities) and the GA's noisy statevector fitness
+ * (reference genetic_v3.py:619-627).  qk_evaluate (f32 != 0: qk_evaluate_f32) with the noise model applied on
+ * the device, band by band behind the Gram launches, before K leaves the GPU.  Y == NULL: symmetric draws,
+ * unit diagonal; otherwise every entry of the N x M block is drawn independently.
+ */
+int qk_evaluate_noisy(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,
+                      int n_features, int f32, int mode, double param, uint64_t seed, double* K_host);
 
 /*
  * Replaces: one GA generation's fitness evaluations (pygad calls fitness_func once per

@@ -78,6 +78,8 @@ SIGNATURES = {
     "qk_kernel_stats_dev": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
     "qk_kernel_stats_noalloc_dev": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
     "qk_kernel_noise_dev": (C.c_int, [_P, _I64, _I64, C.c_int, C.c_double, C.c_uint64, _P]),
+    "qk_kernel_noise_rect_dev": (C.c_int, [_P, _I64, _I64, _I64, C.c_int, C.c_double, C.c_uint64, _P]),
+    "qk_evaluate_noisy": (C.c_int, [_P, _P, _I64, _P, _I64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, _P]),
     "qk_evaluate_batch": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.POINTER(_P),
                                     C.POINTER(qk_batch_opts), C.POINTER(_P), _P]),
 }

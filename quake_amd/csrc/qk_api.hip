@@ -191,6 +191,7 @@ extern "C" int qk_circuit_plan_summary(const qk_circuit* c, char* buf, int len) 
              std::to_string(n_other);
     }
     s += c->rdm_plan ? "; rdm_plan yes" : "; rdm_plan no";
+    s += c->wave_blob.empty() ? "; wave_program no" : "; wave_program yes";
     std::snprintf(buf, (size_t)len, "%s", s.c_str());
     return QK_OK;
 }
@@ -269,7 +270,14 @@ int side_streams(hipStream_t* compute, hipStream_t* copy) {
 // bands).  A band's rows are final once its launch has finished -- everything left of its diagonal
 // block was written by earlier bands -- so the host copies band b while the GPU computes band b + 1.
 // f32: the statevectors are complex64 (qk_gram32_jobs_dev).
-int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t D, bool f32, double* K_host) {
+struct NoiseSpec {
+    int mode = QK_NOISE_NONE;
+    double param = 0.0;
+    uint64_t seed = 0;
+};
+
+int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t D, bool f32, double* K_host,
+                 const NoiseSpec& noise = NoiseSpec()) {
     const bool sym = (dPy == nullptr);
     const size_t esz = f32 ? 8 : 16;
     auto launch = f32 ? qk_gram32_jobs_dev : qk_gram_jobs_dev;
@@ -286,8 +294,9 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
         std::memset(&job, 0, sizeof(job));
         job.A = dPx; job.B = sym ? dPx : dPy; job.K = K;
         job.ma = N; job.nb = M; job.ldk = M; job.flags = sym ? QK_GRAM_SYMMETRIC : 0;
-        const int rc1 = launch(&job, 1, D, nullptr);
+        int rc1 = launch(&job, 1, D, nullptr);
         if (rc1) return rc1;
+        if ((rc1 = launch_noise(K, 0, N, M, M, sym, noise.mode, noise.param, noise.seed, nullptr))) return rc1;
         QK_HIP(hipMemcpy(K_host, K, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));
         return QK_OK;
     }
@@ -336,6 +345,10 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
         }
         rc = launch(jobs, nj, D, compute);
         if (rc != QK_OK) break;
+        // a band's draws: its rows right of the diagonal, mirrored into the later bands' rows (symmetric), or all of
+        // its rows (cross block); ordered behind the band's Gram launch on the same stream
+        rc = launch_noise(K, r0, r1, M, M, sym, noise.mode, noise.param, noise.seed, compute);
+        if (rc != QK_OK) break;
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
             rc = fail(QK_ERR_HIP, "gram_to_host: cannot create event");
@@ -369,13 +382,15 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
 }  // namespace
 }  // namespace qk
 
-extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,
-                           int n_features, double* K_host) {
-    if (!c || !K_host) return fail(QK_ERR_INVALID, "qk_evaluate: null pointer");
+namespace qk {
+namespace {
+int evaluate_host(const char* who, const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M, int n_features,
+                  bool f32, const NoiseSpec& noise, double* K_host) {
+    if (!c || !K_host) return fail(QK_ERR_INVALID, std::string(who) + ": null pointer");
     if (n_features != c->n_params)
         return fail(QK_ERR_INVALID, "x_vec and class feature map have incompatible dimensions");
-    if (N < 0 || (Y && M < 0)) return fail(QK_ERR_INVALID, "qk_evaluate: negative row count");
-    if (c->n_params > 0 && ((N && !X))) return fail(QK_ERR_INVALID, "qk_evaluate: X is null");
+    if (N < 0 || (Y && M < 0)) return fail(QK_ERR_INVALID, std::string(who) + ": negative row count");
+    if (c->n_params > 0 && ((N && !X))) return fail(QK_ERR_INVALID, std::string(who) + ": X is null");
     const bool sym = (Y == nullptr);
     if (sym) M = N;
     if (N == 0 || M == 0) return QK_OK;
@@ -385,24 +400,47 @@ extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, cons
     const double t_begin = now_s();
     const int F = c->n_params;
     const int64_t D = (int64_t)1 << c->n_qubits;
+    const size_t esz = f32 ? 8 : 16;
     {
-        DevBuf dX, dY, dPx, dPy;
+        DevBuf dX, dY, dPx, dPy, dWs;
+        // FP32 statevectors of a multi-pass circuit are rounded from an FP64 workspace
+        const int64_t ws_rows = (f32 && c->passes.size() > 1) ? std::max(N, M) : 0;
+        if (ws_rows) QK_HIP(dWs.alloc((size_t)ws_rows * D * 16));
+        auto simulate = [&](const double* x_dev, int64_t rows, void* psi) {
+            const double t0 = now_s();
+            const int r = f32 ? qk_simulate_c64_dev(c, x_dev, rows, F, psi, dWs.p, nullptr)
+                              : qk_simulate_dev(c, x_dev, rows, F, psi, nullptr);
+            g_profile.t[2] += now_s() - t0;
+            return r;
+        };
         if ((rc = upload_X(X, N, F, dX))) return rc;
-        QK_HIP(dPx.alloc((size_t)N * D * 16));
-        double t0 = now_s();
-        if ((rc = qk_simulate_dev(c, (const double*)dX.p, N, F, dPx.p, nullptr))) return rc;
-        g_profile.t[2] += now_s() - t0;
+        QK_HIP(dPx.alloc((size_t)N * D * esz));
+        if ((rc = simulate((const double*)dX.p, N, dPx.p))) return rc;
         if (!sym) {
             if ((rc = upload_X(Y, M, F, dY))) return rc;
-            QK_HIP(dPy.alloc((size_t)M * D * 16));
-            t0 = now_s();
-            if ((rc = qk_simulate_dev(c, (const double*)dY.p, M, F, dPy.p, nullptr))) return rc;
-            g_profile.t[2] += now_s() - t0;
+            QK_HIP(dPy.alloc((size_t)M * D * esz));
+            if ((rc = simulate((const double*)dY.p, M, dPy.p))) return rc;
         }
-        rc = gram_to_host(dPx.p, N, sym ? nullptr : dPy.p, M, D, false, K_host);
+        rc = gram_to_host(dPx.p, N, sym ? nullptr : dPy.p, M, D, f32, K_host, noise);
     }
     g_profile.t[6] = now_s() - t_begin;
     return rc;
+}
+}  // namespace
+}  // namespace qk
+
+extern "C" int qk_evaluate(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,
+                           int n_features, double* K_host) {
+    return evaluate_host("qk_evaluate", c, X, N, Y, M, n_features, false, NoiseSpec(), K_host);
+}
+
+extern "C" int qk_evaluate_noisy(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M, int n_features,
+                                 int f32, int mode, double param, uint64_t seed, double* K_host) {
+    NoiseSpec noise;
+    noise.mode = mode; noise.param = param; noise.seed = seed;
+    if (mode != QK_NOISE_NONE && mode != QK_NOISE_GAUSSIAN && mode != QK_NOISE_SHOTS)
+        return fail(QK_ERR_INVALID, "qk_evaluate_noisy: unknown noise mode");
+    return evaluate_host("qk_evaluate_noisy", c, X, N, Y, M, n_features, f32 != 0, noise, K_host);
 }
 
 // Development hook (not in the public header): the itemised wall time of the calling thread's last qk_evaluate /
@@ -415,29 +453,7 @@ extern "C" int qk_evaluate_profile(double* out, int len) {
 
 extern "C" int qk_evaluate_f32(const qk_circuit* c, const double* X, int64_t N, const double* Y, int64_t M,
                                int n_features, double* K_host) {
-    if (!c || !K_host) return fail(QK_ERR_INVALID, "qk_evaluate_f32: null pointer");
-    if (n_features != c->n_params)
-        return fail(QK_ERR_INVALID, "x_vec and class feature map have incompatible dimensions");
-    if (N < 0 || (Y && M < 0)) return fail(QK_ERR_INVALID, "qk_evaluate_f32: negative row count");
-    if (c->n_params > 0 && ((N && !X))) return fail(QK_ERR_INVALID, "qk_evaluate_f32: X is null");
-    const bool sym = (Y == nullptr);
-    if (sym) M = N;
-    if (N == 0 || M == 0) return QK_OK;
-    int rc = check_device();
-    if (rc) return rc;
-    const int F = c->n_params;
-    const int64_t D = (int64_t)1 << c->n_qubits;
-    DevBuf dX, dY, dPx, dPy, dWs;
-    if (c->passes.size() > 1) QK_HIP(dWs.alloc((size_t)std::max(N, M) * D * 16));
-    if ((rc = upload_X(X, N, F, dX))) return rc;
-    QK_HIP(dPx.alloc((size_t)N * D * 8));
-    if ((rc = qk_simulate_c64_dev(c, (const double*)dX.p, N, F, dPx.p, dWs.p, nullptr))) return rc;
-    if (!sym) {
-        if ((rc = upload_X(Y, M, F, dY))) return rc;
-        QK_HIP(dPy.alloc((size_t)M * D * 8));
-        if ((rc = qk_simulate_c64_dev(c, (const double*)dY.p, M, F, dPy.p, dWs.p, nullptr))) return rc;
-    }
-    return gram_to_host(dPx.p, N, sym ? nullptr : dPy.p, M, D, true, K_host);
+    return evaluate_host("qk_evaluate_f32", c, X, N, Y, M, n_features, true, NoiseSpec(), K_host);
 }
 
 extern "C" int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t N, int n_features, double gamma,

@@ -198,30 +198,34 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         std::vector<WaveInit> winit(n, WaveInit{-1, -1});
         std::vector<WaveExpr> wexprs(n_expr);
         for (int e = 0; e < n_expr; ++e) wexprs[e] = WaveExpr{expr_off[e], expr_off[e + 1] - expr_off[e], 1.0};
-        auto half = [&](int e) { if (e >= 0) wexprs[e].scale = 0.5; };
+        // one scale per expression: a program that feeds ONE expression to a half-angle gate (rx / ry / rz) and to a
+        // full-angle one (p, the ZZ phase) cannot use this format (the LDS simulator scales per gate, so it runs there)
+        std::vector<uint8_t> used_as(n_expr, 0);
+        auto half = [&](int e) { if (e >= 0) { wexprs[e].scale = 0.5; used_as[e] |= 1; } };
+        auto full = [&](int e) { if (e >= 0) used_as[e] |= 2; };
         std::vector<WaveComp> wcomps;
         std::vector<WaveFactor> wfacts;
         for (const auto& fs : comps) {
             wcomps.push_back(WaveComp{(int32_t)wfacts.size(), (int32_t)fs.size()});
             for (const Factor& f : fs) {
                 wfacts.push_back(WaveFactor{f.gate, f.expr});
-                if (f.gate != QK_P) half(f.expr);
+                if (f.gate != QK_P) half(f.expr); else full(f.expr);
             }
         }
         for (const Item& g : inits) {
             winit[g.q0] = WaveInit{g.gate, g.expr};
-            if (g.gate != QK_UC) half(g.expr);
+            if (g.gate != QK_UC) { if (g.gate != QK_P) half(g.expr); else full(g.expr); }
         }
         for (const Proto& p : seq) {
             if (p.diag) {
                 wops.push_back(WaveOp{WV_DIAG, (int32_t)wterms.size(), (int32_t)p.terms.size(), -1});
                 for (const Item& t : p.terms) {
                     wterms.push_back(WaveTerm{t.kind, t.q0, t.q1 >= 0 ? t.q1 : 0, t.expr});
-                    if (t.kind == TM_RZ) half(t.expr);
+                    if (t.kind == TM_RZ) half(t.expr); else full(t.expr);
                 }
             } else if (p.nd.kind == ST_U1) {
                 wops.push_back(WaveOp{WV_U1, p.nd.q0, p.nd.gate, p.nd.expr});
-                if (p.nd.gate != QK_UC) half(p.nd.expr);
+                if (p.nd.gate != QK_UC) { if (p.nd.gate != QK_P) half(p.nd.expr); else full(p.nd.expr); }
             } else {
                 wops.push_back(WaveOp{p.nd.kind == ST_CX ? WV_CX : WV_ECR, p.nd.q0, p.nd.q1, -1});
             }
@@ -247,6 +251,13 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         H.off_comps = (int32_t)off;    off = pad8(off + wcomps.size() * sizeof(WaveComp));
         H.off_facts = (int32_t)off;    off = pad8(off + wfacts.size() * sizeof(WaveFactor));
         H.bytes = (int32_t)off;
+        bool fits = true;
+        for (int e = 0; e < n_expr; ++e) fits = fits && used_as[e] != 3;
+        // dynamic LDS of a launch: the (cos, sin) and composite tables of spw samples plus the staged blob (a batch
+        // stages the largest blob of its jobs, at most kWaveStageMax); a circuit beyond that runs on the LDS simulator
+        const size_t table_bytes = (size_t)16 * std::max(1, H.spw * (H.n_exprs + 4 * H.n_comps));
+        fits = fits && table_bytes + (size_t)kWaveStageMax <= (size_t)kWaveLdsLimit;
+      if (fits) {
         c.wave_blob.assign(off / 8, 0);
         char* base = (char*)c.wave_blob.data();
         std::memcpy(base, &H, sizeof(H));
@@ -259,6 +270,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         if (!wcomps.empty()) std::memcpy(base + H.off_comps, wcomps.data(), wcomps.size() * sizeof(WaveComp));
         if (!wfacts.empty()) std::memcpy(base + H.off_facts, wfacts.data(), wfacts.size() * sizeof(WaveFactor));
         c.wave_spw = H.spw;
+      }
     }
 
     // ---- 3. passes --------------------------------------------------------

@@ -211,6 +211,9 @@ struct EpiJob {
 };
 int launch_batch_epilogue(const EpiJob* table_dev, int count, int noise_mode, double noise_param, bool want_stats,
                           hipStream_t stream);
+// noise on rows [i0, i1) of a matrix with `cols` columns (symmetric: entries right of the diagonal, mirrored)
+int launch_noise(double* K, int64_t i0, int64_t i1, int64_t cols, int64_t ldk, bool symmetric, int mode, double param,
+                 uint64_t seed, hipStream_t stream);
 // qk_wave.hip
 int wave_nreg_class(int n_qubits);
 size_t wave_lds_bytes(const qk_circuit& c);   // the (cos, sin) table of one unit of work

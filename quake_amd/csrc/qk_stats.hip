@@ -127,16 +127,39 @@ __device__ __forceinline__ double noisy_value(double v, int64_t i, int64_t j, in
     return (double)hits / (double)shots;
 }
 
-__global__ void __launch_bounds__(256) noise_kernel(double* __restrict__ K, int64_t N, int64_t ldk, int mode, double param,
-                                                    uint32_t k0, uint32_t k1) {
-    // 16 x 16 thread tiles over the upper triangle; (i, j) with i < j
+// rows [i0, i1) of a matrix with `cols` columns, 16 x 16 thread tiles.  Symmetric: the entries right of the diagonal
+// are drawn and mirrored (the diagonal stays exact); otherwise every entry is drawn.  The Philox counter of an entry
+// is its (row, column) in the WHOLE matrix, so a matrix sampled band by band equals the one sampled in one launch.
+__global__ void __launch_bounds__(256) noise_kernel(double* __restrict__ K, int64_t i0, int64_t i1, int64_t cols, int64_t ldk,
+                                                    int symmetric, int mode, double param, uint32_t k0, uint32_t k1) {
     const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
-    const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (i >= N || j >= N || i >= j) return;
+    const int64_t i = i0 + (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= i1 || j >= cols || (symmetric && i >= j)) return;
     const double out = noisy_value(K[i * ldk + j], i, j, mode, param, k0, k1);
     K[i * ldk + j] = out;
-    K[j * ldk + i] = out;
+    if (symmetric) K[j * ldk + i] = out;
 }
+
+}  // namespace
+int launch_noise(double* K, int64_t i0, int64_t i1, int64_t cols, int64_t ldk, bool symmetric, int mode, double param,
+                 uint64_t seed, hipStream_t stream) {
+    if (mode == QK_NOISE_NONE || i1 <= i0 || cols < 1) return QK_OK;
+    if (mode == QK_NOISE_GAUSSIAN) {
+        if (!(param >= 0.0)) return fail(QK_ERR_INVALID, "noise: negative standard deviation");
+    } else if (mode == QK_NOISE_SHOTS) {
+        if (!(param >= 1.0) || param > 1e9) return fail(QK_ERR_INVALID, "noise: shots must be in 1..1e9");
+    } else {
+        return fail(QK_ERR_INVALID, "noise: unknown noise mode");
+    }
+    if (i1 > (int64_t)1 << 32 || cols > (int64_t)1 << 32) return fail(QK_ERR_UNSUPPORTED, "noise: matrix too large for the counter layout");
+    const int64_t tx = (cols + 15) / 16, ty = (i1 - i0 + 15) / 16;
+    if (ty > 65535) return fail(QK_ERR_UNSUPPORTED, "noise: more than 1048560 rows in one launch");     // grid.y limit
+    hipLaunchKernelGGL(noise_kernel, dim3((unsigned)tx, (unsigned)ty), dim3(256), 0, stream, K, i0, i1, cols, ldk,
+                       symmetric ? 1 : 0, mode, param, (uint32_t)seed, (uint32_t)(seed >> 32));
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+namespace {
 
 // One GA generation's epilogue in ONE launch: block g owns chromosome g's (small) kernel matrix -- noise on the
 // upper triangle (mirrored), then the statistics of the noisy matrix, reduced inside the block in a fixed order.
@@ -229,11 +252,20 @@ constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 double* g_scratch_ptr[kMaxDevices] = {nullptr};
 
-// the scratch array's address on the current device (looked up on the first call there)
-int scratch_on_current_device(double** out) {
+// the scratch array's address on the current device (looked up on the first call there).  Every GPU holds its own
+// copy of the array, so the copy must be the one of the GPU that K lives on: a K on another device than the current
+// one is refused here instead of handing the kernels an address that is not mapped where they run.
+int scratch_on_current_device(const void* K, double** out) {
     int dev = -1;
     QK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return fail(QK_ERR_UNSUPPORTED, "qk_kernel_stats_noalloc_dev: device index out of range");
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, K) != hipSuccess) {
+        (void)hipGetLastError();      // not a pointer HIP knows: the launch below reports what is wrong with it
+    } else if (at.type == hipMemoryTypeDevice && at.device != dev) {
+        return fail(QK_ERR_INVALID, "qk_kernel_stats_noalloc_dev: K lives on device " + std::to_string(at.device) +
+                                        " but device " + std::to_string(dev) + " is current (hipSetDevice first)");
+    }
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
         void* p = nullptr;
@@ -255,7 +287,7 @@ extern "C" int qk_kernel_stats_noalloc_dev(const double* K, int64_t N, int64_t l
         return fail(QK_ERR_UNSUPPORTED, "qk_kernel_stats_noalloc_dev: N exceeds QK_STATS_NOALLOC_MAX_N (131072 rows); "
                                         "use qk_kernel_stats_dev with a caller-provided workspace");
     double* ws = nullptr;
-    const int rc = scratch_on_current_device(&ws);
+    const int rc = scratch_on_current_device(K, &ws);
     if (rc) return rc;
     // same kernels, same block count and reduction tree as qk_kernel_stats_dev: bitwise the same sums.
     // Every partial the final kernel reads is written by the partial kernel of THIS call (blocks entries),
@@ -270,22 +302,12 @@ extern "C" int qk_kernel_stats_noalloc_dev(const double* K, int64_t N, int64_t l
 extern "C" int qk_kernel_noise_dev(double* K, int64_t N, int64_t ldk, int mode, double param, uint64_t seed, void* stream) {
     if (!K) return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: null pointer");
     if (N < 1 || ldk < N) return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: bad shape");
-    if (mode == QK_NOISE_NONE) return QK_OK;
-    if (mode == QK_NOISE_GAUSSIAN) {
-        if (!(param >= 0.0)) return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: negative standard deviation");
-    } else if (mode == QK_NOISE_SHOTS) {
-        if (!(param >= 1.0) || param > 1e9) return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: shots must be in 1..1e9");
-    } else {
-        return fail(QK_ERR_INVALID, "qk_kernel_noise_dev: unknown noise mode");
-    }
-    if (N > (int64_t)1 << 32) return fail(QK_ERR_UNSUPPORTED, "qk_kernel_noise_dev: N too large for the counter layout");
-    const int64_t tiles = (N + 15) / 16;
-    if (tiles > 65535) {
-        // grid.y limit: noise models are meant for GA-sized matrices
-        return fail(QK_ERR_UNSUPPORTED, "qk_kernel_noise_dev: N > 1048560 not supported");
-    }
-    hipLaunchKernelGGL(noise_kernel, dim3((unsigned)tiles, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, K, N, ldk, mode,
-                       param, (uint32_t)seed, (uint32_t)(seed >> 32));
-    QK_HIP(hipGetLastError());
-    return QK_OK;
+    return launch_noise(K, 0, N, N, ldk, true, mode, param, seed, (hipStream_t)stream);
+}
+
+extern "C" int qk_kernel_noise_rect_dev(double* K, int64_t rows, int64_t cols, int64_t ldk, int mode, double param,
+                                        uint64_t seed, void* stream) {
+    if (!K) return fail(QK_ERR_INVALID, "qk_kernel_noise_rect_dev: null pointer");
+    if (rows < 1 || cols < 1 || ldk < cols) return fail(QK_ERR_INVALID, "qk_kernel_noise_rect_dev: bad shape");
+    return launch_noise(K, 0, rows, cols, ldk, false, mode, param, seed, (hipStream_t)stream);
 }

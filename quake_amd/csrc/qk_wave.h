@@ -8,6 +8,8 @@ namespace qk {
 
 constexpr int kWaveMaxQubits = 10;      // 64 lanes x 16 amplitudes
 constexpr int kWaveMaxExprs = 2048;     // (cos, sin) pairs of one sample in LDS: 32 KiB
+constexpr int kWaveStageMax = 24 * 1024;   // largest blob staged in LDS
+constexpr int kWaveLdsLimit = 64 * 1024;   // dynamic LDS of a launch (the default limit; never raised): tables + staged blob
 
 enum WaveOpKind : int32_t { WV_U1 = 0, WV_CX = 1, WV_ECR = 2, WV_DIAG = 3 };
 

@@ -39,7 +39,6 @@ struct WaveArgs {
     int64_t total_units;
 };
 
-constexpr int kWaveStageMax = 24 * 1024;   // largest blob staged in LDS
 
 namespace {
 

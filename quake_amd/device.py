@@ -217,15 +217,24 @@ def kernel_stats(K: torch.Tensor, labels: Optional[torch.Tensor] = None) -> torc
     return out
 
 
-def kernel_noise_(K: torch.Tensor, mode: str, param: float, seed: int = 0) -> torch.Tensor:
-    """In-place noise on a symmetric device K: ``mode`` = "gaussian" (param = std, reference
-    genetic_v3.py:620-627) or "shots" (param = shots, the QPU-style P(0...0) estimate)."""
+def kernel_noise_(K: torch.Tensor, mode: str, param: float, seed: int = 0, symmetric: bool = True) -> torch.Tensor:
+    """In-place noise on a device K: ``mode`` = "gaussian" (param = std, reference genetic_v3.py:620-627) or "shots"
+    (param = shots, the QPU-style P(0...0) estimate).  ``symmetric`` (a square train kernel): the entries right of
+    the diagonal are drawn and mirrored, the diagonal stays exact; otherwise (a test-versus-train block of any
+    shape) every entry is drawn."""
     K = from_dlpack(K)
     _require_gpu(K)
-    if K.dtype != torch.float64 or K.dim() != 2 or K.shape[0] != K.shape[1] or K.stride(1) != 1:
-        raise ValueError("K must be a square float64 matrix with unit column stride")
+    if K.dtype != torch.float64 or K.dim() != 2 or K.stride(1) != 1 or K.shape[0] < 1 or K.shape[1] < 1:
+        raise ValueError("K must be a float64 matrix with unit column stride")
+    if symmetric and K.shape[0] != K.shape[1]:
+        raise ValueError("a symmetric K must be square")
     code = {"gaussian": _lib.NOISE_GAUSSIAN, "shots": _lib.NOISE_SHOTS}[mode]
-    N = K.shape[0]
-    _lib.check(_lib.load().qk_kernel_noise_dev(_dp(K), N, K.stride(0) if N > 1 else N, code, float(param),
-                                               int(seed) & (2**64 - 1), _stream_ptr()))
+    rows, cols = K.shape
+    ldk = K.stride(0) if rows > 1 else cols
+    if symmetric:
+        _lib.check(_lib.load().qk_kernel_noise_dev(_dp(K), rows, ldk, code, float(param), int(seed) & (2**64 - 1),
+                                                   _stream_ptr()))
+    else:
+        _lib.check(_lib.load().qk_kernel_noise_rect_dev(_dp(K), rows, cols, ldk, code, float(param),
+                                                        int(seed) & (2**64 - 1), _stream_ptr()))
     return K

@@ -203,18 +203,20 @@ class HipFidelityKernel:
                 raise ValueError(f"out must be a writable C-contiguous float64 array of shape {want}")
             if self._shots is not None or (y is None and self._enforce_psd):
                 raise ValueError("out= is not supported with shots or enforce_psd")
-        if self._shots is not None:
-            # FidelityStatevectorKernel(shots=...): each entry becomes Binomial(shots, K_ij) / shots.
-            # Sampled on the device (qk_kernel_noise_dev) for the symmetric matrix.
-            self._shot_calls += 1
-            seed = (self._shot_seed + self._shot_calls) & (2**64 - 1)
-            if y is not None:
-                return self._sampled_cross_block(x, y, seed)
-            Ks, _ = evaluate_population([self._bound], [x], noise=("shots", self._shots), seed=seed)
-            return Ks[0]
         lib = _lib.load()
         circ = self._circuit()
         n, m = x.shape[0], (x.shape[0] if y is None else y.shape[0])
+        if self._shots is not None:
+            # FidelityStatevectorKernel(shots=...): each entry becomes Binomial(shots, K_ij) / shots, drawn on the
+            # device behind the Gram launches (qk_evaluate_noisy): symmetric draws with an exact diagonal for
+            # evaluate(x), independent draws for every entry of a cross block
+            self._shot_calls += 1
+            seed = (self._shot_seed + self._shot_calls) & (2**64 - 1)
+            K = _lib.host_empty((n, m))
+            _lib.check(lib.qk_evaluate_noisy(
+                circ.handle, _lib.ptr(x), n, _lib.ptr(y) if y is not None else None, m, x.shape[1],
+                0 if self._precision == "double" else 1, _lib.NOISE_SHOTS, float(self._shots), seed, _lib.ptr(K)))
+            return K
         K = out if out is not None else _lib.host_empty((n, m))
         _lib.check((lib.qk_evaluate if self._precision == "double" else lib.qk_evaluate_f32)(
             circ.handle, _lib.ptr(x), n,
@@ -222,14 +224,6 @@ class HipFidelityKernel:
         _pin_equal_rows(K, x, y)
         if y is None and self._enforce_psd:
             K = self._make_psd(K)
-        return K
-
-    def _sampled_cross_block(self, x: np.ndarray, y: np.ndarray, seed: int) -> np.ndarray:
-        """Finite-shot estimate of a cross block: the exact block is embedded in the symmetric matrix of the stacked
-        rows [x; y], sampled there by the device epilogue (independent draws per entry) and cut out again."""
-        n, m = x.shape[0], y.shape[0]
-        Ks, _ = evaluate_population([self._bound], [np.concatenate([x, y], axis=0)], noise=("shots", self._shots), seed=seed)
-        K = np.ascontiguousarray(Ks[0][:n, n:])
         return K
 
     def statevectors(self, x_vec) -> np.ndarray:

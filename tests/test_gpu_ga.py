@@ -189,6 +189,35 @@ def test_finite_shot_kernel_object(data8):
     zc = (sc[ok] - ec[ok]) / np.sqrt(ec[ok] * (1 - ec[ok]) / 4000)
     assert ok.sum() >= 20 and np.abs(zc).max() < 6 and abs(zc.std() - 1) < 0.4
     assert np.abs(sc - ec).max() < 0.06
+    # the draws are keyed by (row, column, seed): the cross block equals the exact block sampled in one device launch
+    seed9 = (9 + 1) & (2**64 - 1)
+    one = qdev.kernel_noise_(torch.from_numpy(ec).cuda(), "shots", 4000, seed=seed9, symmetric=False).cpu().numpy()
+    assert np.array_equal(one, sc)
+
+
+def test_finite_shot_kernel_in_bands_equals_one_launch():
+    """qk_evaluate_noisy draws band by band behind the Gram launches (2500 rows = two bands); the result equals the
+    exact matrix sampled by one launch of the device entry point with the same seed, for both precisions' plumbing."""
+    from quake_amd import featuremaps as fm
+    from quake_amd.circuit import ParameterVector
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1.5, 1.5, size=(2500, 6))
+    Y = rng.uniform(-1.5, 1.5, size=(2100, 6))
+    circ = fm.zz_featuremap(ParameterVector("x", 6), 6, 1)
+    exact = HipFidelityKernel(circ).evaluate(X)
+    s = HipFidelityKernel(circ, shots=500, seed=41).evaluate(X)
+    ref = qdev.kernel_noise_(torch.from_numpy(exact).cuda(), "shots", 500, seed=42).cpu().numpy()
+    off = ~np.eye(2500, dtype=bool)
+    assert np.array_equal(s[off], ref[off]) and np.array_equal(s, s.T) and np.abs(np.diag(s) - 1).max() < 1e-12
+    ec = HipFidelityKernel(circ).evaluate(Y, X)
+    sc = HipFidelityKernel(circ, shots=500, seed=41).evaluate(Y, X)
+    refc = qdev.kernel_noise_(torch.from_numpy(ec).cuda(), "shots", 500, seed=42, symmetric=False).cpu().numpy()
+    assert np.array_equal(sc, refc)
+    # precision="single" is honoured: draws from the FP32 fidelities (equal to the FP64 ones to 1e-5, so the counts
+    # differ in a few entries at most), not silently from the FP64 path
+    s32 = HipFidelityKernel(circ, shots=500, seed=41, precision="single").evaluate(Y, X)
+    assert s32.shape == sc.shape and np.abs(s32 * 500 - np.round(s32 * 500)).max() < 1e-9
+    assert (s32 != sc).mean() < 0.02 and np.abs(s32 - sc).max() <= 2 / 500
 
 
 def test_kernel_alignment_loss_and_bookkeeping():
@@ -223,6 +252,18 @@ def test_kernel_alignment_loss_and_bookkeeping():
     assert abs(result["optimal_value"] - oracle_loss(aligned.parameter_values)) < 1e-9
     assert abs(result["optimal_value"] - result["initial_value"]) > 1e-6
     assert all(np.isfinite(h["fx"]) and h["stepsize"] > 0 for h in history)
+    # the search moves the right way: one hand-set SPSA step (no random draw: start, perturbation direction and
+    # gains fixed) computed from the GPU's two losses lowers the ORACLE's loss, for both perturbation directions
+    x0 = np.array([0.3, -0.2])
+    for delta in (np.array([1.0, -1.0]), np.array([1.0, 1.0])):
+        class Fixed:                      # spsa_minimize draws its direction with rng.choice
+            def choice(self, values, size):
+                return delta
+        x1, hist1 = alignment.spsa_minimize(lambda tp, tm: tuple(
+            alignment.svc_loss(Kt, y, 1.0) for Kt in evaluate_population(
+                [fmap.assign_parameters(dict(zip(kernel.training_parameters, t))) for t in (tp, tm)], [X, X])[0]),
+            x0, maxiter=1, rng=Fixed(), learning_rate=0.01, perturbation=0.05)
+        assert hist1[0]["stepsize"] > 1e-4 and oracle_loss(x1) < oracle_loss(x0) - 1e-3
     # the aligned kernel is an ordinary kernel object: same numbers as the oracle at the found theta
     bound = fmap.assign_parameters(dict(zip(kernel.training_parameters, aligned.parameter_values)))
     ref = O.fidelity_kernel(O.simulate(O_ops(bound), 2, X))

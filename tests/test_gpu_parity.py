@@ -601,3 +601,19 @@ def test_host_path_row_bands(precision, tol):
     assert np.array_equal(K, K.T) and (np.diag(K) == 1.0).all()
     assert np.abs(K - ref).max() < tol
     assert np.abs(k.evaluate(X, Y) - O.evaluate(oops, n, X, Y)).max() < tol
+
+
+def test_one_expression_feeding_half_and_full_angle_gates():
+    """A C-ABI program whose rz and p read ONE expression slot (compile() never emits that): the planner keeps it off
+    the wave-resident format (one scale per expression) and the result still equals the oracle."""
+    from quake_amd import _lib
+    from tests._helpers import compiled_to_oracle_ops
+    from tests.test_planner import _shared_angle_program
+    compiled = _shared_angle_program()
+    h = _lib.CircuitHandle(compiled)
+    assert "wave_program no" in h.plan_summary
+    X = np.random.default_rng(8).uniform(-3, 3, size=(333, 1))
+    psi = _lib.host_empty((333, 4), np.complex128)
+    _lib.check(_lib.load().qk_simulate(h.handle, _lib.ptr(X), 333, 1, _lib.ptr(psi)))
+    ref = O.simulate(compiled_to_oracle_ops(compiled), 2, X)
+    assert np.abs(psi - ref).max() < 1e-12

@@ -57,3 +57,41 @@ def test_genome_pass_runs_wide_and_keeps_a_plan_for_the_fused_rdm_mode():
     if p[0]["u1"] + p[0]["other"] > 0:      # butterflies or swaps beyond the product state: 512 threads, radix 4
         assert p[0]["T"] == 512 and p[0]["narrow"] == 1 and p[0]["maxg"] == 2 and p[0]["ng"] <= 2, s
         assert "rdm_plan yes" in s
+
+
+def _shared_angle_program():
+    """rz(x0) and p(x0) on two qubits reading ONE expression slot: legal through the C-ABI (compile() never emits it)."""
+    from quake_amd.circuit import CompiledCircuit, GATE_CODES, QuantumCircuit
+    x = ParameterVector("x", 1)
+    probe = QuantumCircuit(2)
+    probe.rz(x[0], 0)
+    one = probe.compile()            # the postfix program of the single expression x0
+    ops = np.array([[GATE_CODES["h"], 0, -1, -1], [GATE_CODES["h"], 1, -1, -1], [GATE_CODES["cx"], 0, 1, -1],
+                    [GATE_CODES["rz"], 0, -1, 0], [GATE_CODES["p"], 1, -1, 0], [GATE_CODES["cx"], 1, 0, -1],
+                    [GATE_CODES["h"], 0, -1, -1]], dtype=np.int32)
+    return CompiledCircuit(n_qubits=2, n_params=1, ops=ops, prog=one.prog, expr_off=one.expr_off, consts=one.consts)
+
+
+def test_wave_program_is_refused_when_one_expression_feeds_half_and_full_angle_gates():
+    assert "wave_program yes" in plan(zz(4, 2))[0]
+    s = _lib.CircuitHandle(_shared_angle_program()).plan_summary
+    assert "wave_program no" in s
+
+
+def test_wave_program_is_refused_when_its_tables_exceed_the_dynamic_lds_limit():
+    """A long narrow circuit: (cos, sin) pairs and composite matrices of one sample beyond 40 KiB (64 KiB less the
+    staged program) -> the LDS simulator runs it instead of a launch that HIP would refuse."""
+    from quake_amd.circuit import QuantumCircuit
+    x = ParameterVector("x", 3)
+    def narrow(layers):
+        qc = QuantumCircuit(3)
+        for k in range(layers):
+            for q in range(3):
+                qc.rx(x[q] * (k + 1), q)
+                qc.rz(x[(q + 1) % 3], q)
+                qc.ry(x[q] + 0.1 * k, q)
+            qc.cx(0, 1)
+            qc.cx(1, 2)
+        return qc
+    assert "wave_program yes" in plan(narrow(20))[0]
+    assert "wave_program no" in plan(narrow(200))[0]       # 1800 expressions + 600 composite matrices: 66 KiB
