@@ -172,10 +172,8 @@ def gram_kernel_name(rows, D):
     lib.qk_gram_variant_for.restype = C.c_char_p
     lib.qk_gram_variant_for.argtypes = [C.c_int64, C.c_int64]
     name = lib.qk_gram_variant_for(rows, D).decode()
-    return {"dma3m_128x128_w8": "qk::gram_dma_kernel<2,4,4,2,true> (128x128 tiles)",
-            "dma3m_64x64_w4": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles)",
-            "dma3m_64x64_w4_g64": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles, 8x8 tile groups)",
-            "lean3m_64x64_w4": "qk::gram_lean_kernel<2,2,2,2,0> (64x64 tiles)",
+    return {"4m_128x128_w8_bk8": "qk::gram_kernel<2,4,4,2,8,false> (register-staged, circuits under 3 qubits)",
+            "dma3m_64x64_w4_g64": "qk::gram_dma_kernel<2,2,2,2,true> (64x64 tiles, rows beyond 2^22 amplitudes)",
             "ring3_64x64_w4": "qk::gram_ring_kernel<3> (64x64 tiles, 3-stage LDS ring, 3 workgroups per CU)",
             "ring5_64x64_w4": "qk::gram_ring_kernel<5> (64x64 tiles, 5-stage LDS ring, 2 workgroups per CU)"}.get(name, name)
 

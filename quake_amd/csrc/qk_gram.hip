@@ -17,11 +17,13 @@
 // in stages of 8 amplitudes through a ring of 3 or 5 buffers, the barrier of a stage waiting for the next stage
 // only (partial vmcnt), and the k-loop holds no vector-ALU instruction beside the four fragment sums of the
 // 3-multiplication product -- the FP64 MFMA and the FP64 vector ALU share their multipliers, every other VALU
-// instruction there is lost matrix time (profiles/r02_gram_ablation.md).  gram_dma_kernel below
-// (k-tiles of 16 amplitudes, double buffered, 256-byte LDS rows with slot s of row r holding amplitude
-// s ^ (r & 15)) was the round-1 kernel: it serves rows beyond 2^22 amplitudes and A/B runs, gram_lean_kernel is
-// its geometry with the stripped loop, and the register-staged gram_kernel (k-major LDS image with one element
-// of padding per row) serves circuits under 3 qubits.  All of them give the same bits.
+// instruction there is lost matrix time (profiles/r02_gram_ablation.md).  Two more kernels are kept
+// for the shapes the rings do not take: gram_dma_kernel (the round-1 kernel: k-tiles of 16 amplitudes, double
+// buffered, 256-byte LDS rows with slot s of row r holding amplitude s ^ (r & 15); 64-bit addressing) for rows
+// beyond 2^22 amplitudes, and the register-staged gram_kernel (k-major LDS image with one element of padding per
+// row) for circuits under 3 qubits.  All of them give the same bits.  (The kernels that only A/B runs used --
+// 128 x 128 tiles, the "lean" double-buffered loop, other macro-tile shapes -- and the -DQK_GRAM_ABLATE measurement
+// builds left the source after round 2; profiles/r02_gram_ablation.md names the commit that holds them.)
 //
 // Tile schedule (gram_locate): the tiles that have to be computed are listed band by band (8 tile rows),
 // column-major inside a band, and cut into groups of 64 consecutive tiles -- an 8 x 8 macro-tile without dead
@@ -60,7 +62,6 @@ struct GramArgs {
     int lr, lc;  // log2 of the macro-tile shape in block tiles (rows, columns): 4 x 8 for 128 x 128 tiles
     int64_t D;  // amplitudes per row
     int64_t ld; // row stride of A and B in amplitudes (>= D)
-    double* trace;  // timeline builds only (QK_GRAM_ABLATE & 128): 8 doubles per workgroup
     unsigned int* sync;   // ring kernel, long rows: one arrival counter per cohort of 32 workgroups (null: no pacing)
     int sync_shift;       // log2 of the trips of the stage loop (NST stages each) between two meetings of a cohort
 };
@@ -188,15 +189,6 @@ __device__ __forceinline__ bool gram_locate(const GramArgs&, const int64_t bid, 
     return gram_locate((gram_kargs_t)__builtin_amdgcn_kernarg_segment_ptr(), (uint32_t)bid, J, ti, tj);
 }
 
-// Measurement builds only (tools/gram_ablate.sh compiles this file again with -DQK_GRAM_ABLATE=mask into a
-// separate library; the results of such a build are wrong on purpose): bit 0 drops the in-loop DMA, bit 1 the
-// in-loop barrier, bit 2 the in-loop fragment reads (and with them the two VALU adds per fragment), bit 3 points
-// every in-loop DMA at k-tile 0 (always an L2 hit), bit 4 drops the VALU adds only, bit 5 all stores of the epilogue, bit 6 its mirror
-// stores (bits 5 and 6 act on every kernel, bit 3 on gram_dma_kernel and gram_ring_kernel, the others on gram_dma_kernel only).
-#ifndef QK_GRAM_ABLATE
-#define QK_GRAM_ABLATE 0
-#endif
-
 // |.|^2 and the stores.  f64 16x16x4 result layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
 template <int TM, int TN, bool K3M, int NACC>
 __device__ __forceinline__ void gram_epilogue(v4d (&acc)[NACC][TM][TN], const GramJobDev& J, int64_t wrow0,
@@ -204,7 +196,7 @@ __device__ __forceinline__ void gram_epilogue(v4d (&acc)[NACC][TM][TN], const Gr
     double* __restrict__ Kp = J.K;
     double* __restrict__ KTp = J.KT;
     const int64_t ldk = J.ldk, ldkt = J.ldkt, ma = J.ma, nb = J.nb;
-    if constexpr (K3M && (QK_GRAM_ABLATE & (32 | 64)) == 0) {
+    if constexpr (K3M) {
         // A wave whose 16 TM x 16 TN entries all lie inside the block and (symmetric job) strictly above the
         // diagonal -- all but the edge and diagonal tiles -- needs no test per entry, and its addresses are a
         // wave-uniform base (scalar registers and scalar arithmetic) plus one 32-bit lane offset per store
@@ -272,9 +264,8 @@ __device__ __forceinline__ void gram_epilogue(v4d (&acc)[NACC][TM][TN], const Gr
                     if (i > j) continue;      // below the diagonal: written by the mirror store
                     if (i == j) v = 1.0;      // identical statevectors stay exactly 1
                 }
-                if (QK_GRAM_ABLATE & 32) { if (v == 123.456) Kp[0] = v; continue; }
                 Kp[i * ldk + j] = v;
-                if (sym && i != j && !(QK_GRAM_ABLATE & 64)) Kp[j * ldk + i] = v;
+                if (sym && i != j) Kp[j * ldk + i] = v;
                 if (KTp) KTp[j * ldkt + i] = v;
             }
 }
@@ -589,7 +580,7 @@ gram_dma_kernel(GramArgs args) {
         const int cur = (int)(kt & 1);
         // next k-tile straight into the other buffer (nobody reads it during this k-tile);
         // the last iteration re-reads its own tile: branch-free and harmless
-        const int64_t noff = (QK_GRAM_ABLATE & 8) ? 0 : min(kt + 1, ktiles - 1) * C::BK;
+        const int64_t noff = min(kt + 1, ktiles - 1) * C::BK;
         const v2d* S = smem + cur * C::BUF;
         const v2d* Sn = smem + (cur ^ 1) * C::BUF;
 #pragma unroll
@@ -599,16 +590,16 @@ gram_dma_kernel(GramArgs args) {
                 // issued (a, b are dead then) and before P3, also across the barrier
                 double sa[TM], db[TN];
 #pragma unroll
-                for (int m = 0; m < TM; ++m) sa[m] = (QK_GRAM_ABLATE & 16) ? a[m].x : a[m].x + a[m].y;
+                for (int m = 0; m < TM; ++m) sa[m] = a[m].x + a[m].y;
 #pragma unroll
-                for (int n = 0; n < TN; ++n) db[n] = (QK_GRAM_ABLATE & 16) ? b[n].y : b[n].y - b[n].x;
+                for (int n = 0; n < TN; ++n) db[n] = b[n].y - b[n].x;
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
                         acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < 3 && !(QK_GRAM_ABLATE & 1)) issue_dma(cur ^ 1, noff, kk);
+                if (kk < 3) issue_dma(cur ^ 1, noff, kk);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
@@ -617,20 +608,16 @@ gram_dma_kernel(GramArgs args) {
                         acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk < KS - 1) {
-                    if (!(QK_GRAM_ABLATE & 4)) {
 #pragma unroll
-                        for (int m = 0; m < TM; ++m) a[m] = S[a_row + m * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
+                    for (int m = 0; m < TM; ++m) a[m] = S[a_row + m * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
 #pragma unroll
-                        for (int n = 0; n < TN; ++n) b[n] = S[b_row + n * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
-                    }
+                    for (int n = 0; n < TN; ++n) b[n] = S[b_row + n * 256 + xs[kk + 1 < KS ? kk + 1 : 0]];
                 } else {
-                    if (!(QK_GRAM_ABLATE & 2)) __syncthreads();
-                    if (!(QK_GRAM_ABLATE & 4)) {
+                    __syncthreads();
 #pragma unroll
-                        for (int m = 0; m < TM; ++m) a[m] = Sn[a_row + m * 256 + xs[0]];
+                    for (int m = 0; m < TM; ++m) a[m] = Sn[a_row + m * 256 + xs[0]];
 #pragma unroll
-                        for (int n = 0; n < TN; ++n) b[n] = Sn[b_row + n * 256 + xs[0]];
-                    }
+                    for (int n = 0; n < TN; ++n) b[n] = Sn[b_row + n * 256 + xs[0]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -680,176 +667,21 @@ gram_dma_kernel(GramArgs args) {
     gram_epilogue<TM, TN, K3M>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
 }
 
-// ---- "lean" LDS-DMA kernel: the same tiles, arithmetic and LDS image as gram_dma_kernel, with the inner loop
-// stripped of vector-ALU work.  Ablation builds of gram_dma_kernel (tools/gram_ablate.sh) showed
-// that every VALU instruction a wave issues between its MFMAs costs matrix-pipe time (the FP64 MFMA and the FP64
-// vector ALU are the same multipliers; 4 v_add_f64 per k-step = 2.4 %, the 64-bit address adds and readfirstlanes
-// around each DMA instruction another 3.6 %).  Here
-//   * DMA sources are  SGPR base (advanced per k-tile on the scalar ALU) + a per-lane 32-bit offset that never
+// ---- "ring" LDS-DMA kernel: stages of 8 amplitudes in a ring of NST 16 KiB buffers, with an inner loop stripped of
+// vector-ALU work.  Ablation builds of gram_dma_kernel in round 2 showed that every VALU instruction a wave issues
+// between its MFMAs costs matrix-pipe time (the FP64 MFMA and the FP64 vector ALU are the same multipliers; 4 v_add_f64
+// per k-step = 2.4 %, the 64-bit address adds and readfirstlanes around each DMA instruction another 3.6 %).  Here
+//   * DMA sources are  SGPR base (advanced per stage on the scalar ALU) + a per-lane 32-bit offset that never
 //     changes, the LDS destinations are scalar (wave index through readfirstlane once),
-//   * fragment reads use 2 x KS precomputed per-lane LDS addresses with immediate offsets; the k-tile loop is
-//     unrolled by two so that the buffer a k-tile lives in is a compile-time constant,
+//   * fragment reads use precomputed per-lane LDS addresses with immediate offsets; the stage loop is unrolled over
+//     the ring so that the buffer a stage lives in is a compile-time constant,
 //   * loop control is 32-bit scalar,
 // which leaves the TM + TN fragment sums as the only vector-ALU instructions of a k-step.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int SCHED>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
-gram_lean_kernel(GramArgs args) {
-    using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, true>;
-    constexpr int KS = 4;
-    constexpr int NE = C::NA + C::NB;
-    extern __shared__ v2d smem[];  // [2 buffers][A: BM x 16 | B: BN x 16]
-    GramJobDev J;
-    int ti, tj;
-    if (!gram_locate(args, (int64_t)blockIdx.x, J, ti, tj)) return;
-    const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
-
-    [[maybe_unused]] const uint64_t t_start = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const uint32_t D = (uint32_t)args.D, LD = (uint32_t)args.ld;   // the host checks ld <= 2^22: 63 rows x ld x 16 B fit 32 bits
-    const int64_t row0 = (int64_t)ti * C::BM, col0 = (int64_t)tj * C::BN;
-    const int64_t ma = J.ma, nb = J.nb;
-
-    // per-lane byte offsets of this wave's DMA instructions from the tile's first A / B row (rows past the
-    // end are clamped to the last one: their results are never stored)
-    uint32_t vo[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int j = e < C::NA ? e : e - C::NA;
-        const int row = 4 * (wave + C::WAVES * j) + (lane >> 4);
-        const int64_t first = e < C::NA ? row0 : col0, last = (e < C::NA ? ma : nb) - 1;
-        const uint32_t rr = (uint32_t)(min(first + row, last) - first);
-        vo[e] = (rr * LD + (uint32_t)((lane & 15) ^ (row & 15))) * 16u;
-    }
-    const char* Ab = (const char*)J.A + row0 * (int64_t)LD * 16;   // wave-uniform: scalar registers
-    const char* Bb = (const char*)J.B + col0 * (int64_t)LD * 16;
-    char* const lds = (char*)smem;
-    // DMA instruction e of this wave into buffer `buf`, source k-tile at byte offset koff of every row
-    auto dma = [&](int buf, uint32_t koff, int e) __attribute__((always_inline)) {
-        const int j = e < C::NA ? e : e - C::NA;
-        const char* src = (e < C::NA ? Ab : Bb) + koff;
-        char* dst = lds + buf * (C::BUF * 16) + (e < C::NA ? 0 : C::BM * 256) + (wave + C::WAVES * j) * 1024;
-        // (scalar base) + zext(32-bit lane offset) selects the SGPR-base form of the instruction; the empty asm
-        // keeps the zero-extension inside the loop body, where instruction selection can see it
-        asm volatile("" : "+v"(vo[e]));
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + (uint64_t)vo[e]), (lptr_t)dst, 16, 0, 0);
-    };
-    auto dma_part = [&](int buf, uint32_t koff, int kk) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const bool mine = SCHED == 0 ? (e % 3) == kk : SCHED == 1 ? (e / ((NE + 1) / 2)) == kk : kk == 0;
-            if (mine) dma(buf, koff, e);
-        }
-    };
-
-    v4d acc[3][TM][TN];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int n = 0; n < TN; ++n) acc[c][m][n] = (v4d){0, 0, 0, 0};
-
-    const int ktiles = (int)(D >> 4);
-#pragma unroll
-    for (int e = 0; e < NE; ++e) dma(0, 0, e);
-    __syncthreads();
-
-    // fragment byte addresses in buffer 0: element (row * 16 + ((4 kk + lane>>4) ^ (lane & 15)))
-    const int frag_k = lane >> 4, frag_r = lane & 15;
-    typedef const __attribute__((address_space(3))) v2d* lfrag_t;
-    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;    // the LDS address of the image, folded into fa / fb once
-    uint32_t fa[KS], fb[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        const int x = (4 * kk + frag_k) ^ frag_r;
-        fa[kk] = lds0 + (uint32_t)(((wm * (TM * 16) + frag_r) * 16 + x) * 16);
-        fb[kk] = lds0 + (uint32_t)((C::BM * 16 + (wn * (TN * 16) + frag_r) * 16 + x) * 16);
-        asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));   // opaque: otherwise the sums are redone per read
-    }
-    v2d a[TM], b[TN];
-    auto read_frags = [&](int buf, int kk) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < TM; ++m) a[m] = *(lfrag_t)(size_t)(fa[kk] + (uint32_t)(buf * C::BUF * 16 + m * 4096));
-#pragma unroll
-        for (int n = 0; n < TN; ++n) b[n] = *(lfrag_t)(size_t)(fb[kk] + (uint32_t)(buf * C::BUF * 16 + n * 4096));
-    };
-    read_frags(0, 0);
-    [[maybe_unused]] const uint64_t t_first = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
-
-    // one k-tile out of buffer CUR while the DMA fills the other one with the k-tile at row offset koff
-    auto ktile = [&](auto cur_c, uint32_t koff) __attribute__((always_inline)) {
-        constexpr int CUR = decltype(cur_c)::value;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            double sa[TM], db[TN];
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int n = 0; n < TN; ++n)
-                    acc[0][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[0][m][n], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < TM; ++m) sa[m] = a[m].x + a[m].y;
-#pragma unroll
-            for (int n = 0; n < TN; ++n) db[n] = b[n].y - b[n].x;
-            if (kk < KS - 1) dma_part(CUR ^ 1, koff, kk);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int n = 0; n < TN; ++n)
-                    acc[1][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[1][m][n], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kk < KS - 1) {
-                read_frags(CUR, kk + 1 < KS ? kk + 1 : 0);
-            } else {
-                __syncthreads();
-                read_frags(CUR ^ 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int n = 0; n < TN; ++n)
-                    acc[2][m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[m], db[n], acc[2][m][n], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // the last k-tile re-reads itself into the idle buffer: branch-free and harmless
-    int kt = 0;
-    for (; kt + 2 <= ktiles; kt += 2) {
-        ktile(std::integral_constant<int, 0>{}, (uint32_t)min(kt + 1, ktiles - 1) * 256u);
-        ktile(std::integral_constant<int, 1>{}, (uint32_t)min(kt + 2, ktiles - 1) * 256u);
-    }
-    if (kt < ktiles) ktile(std::integral_constant<int, 0>{}, (uint32_t)(ktiles - 1) * 256u);
-    if constexpr ((QK_GRAM_ABLATE & 128) != 0) {
-        // timeline build: wave 0 of every workgroup leaves its 100 MHz timestamps and where it ran in the first
-        // row of a side table the tool passes as KT of a non-symmetric job (8 doubles per workgroup)
-        const uint64_t t_loop = wall_clock64();
-        gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
-        __builtin_amdgcn_s_waitcnt(0);
-        const uint64_t t_end = wall_clock64();
-        if (tid == 0 && args.trace) {
-            double* o = args.trace + (int64_t)blockIdx.x * 8;
-            o[0] = (double)t_start; o[1] = (double)t_first; o[2] = (double)t_loop; o[3] = (double)t_end;
-            o[4] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-            o[5] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-            o[6] = (double)ti; o[7] = (double)tj;
-        }
-        return;
-    }
-    gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
-}
-
-// ---- "ring" LDS-DMA kernel: the lean inner loop over stages of 8 amplitudes in a ring of NST 16 KiB buffers.
 // The DMA of stage h + NST - 1 is issued while stage h is computed and only stage h + 1 is waited for
 // (s_waitcnt vmcnt(4 (NST - 2)): the younger DMA instructions of the wave stay in flight across the barrier), so a
 // load has NST - 1 stages to arrive instead of the remainder of one k-tile.  NST = 3: 48 KiB of LDS, THREE workgroups
 // per CU (three waves per SIMD) -- for short rows, where a tile is over in tens of microseconds and its prologue,
-// epilogue and the restart of the slot (measured with the timeline build: 1, 3.5 and 6 us of a 49 us tile at D = 256)
+// epilogue and the restart of the slot (measured with round 2's timeline build: 1, 3.5 and 6 us of a 49 us tile at D = 256)
 // have to hide behind the other workgroups of the CU.  NST = 5: 80 KiB, two workgroups per CU, four stages of
 // prefetch -- for long rows, where the working set of a third workgroup costs more in L2 than it hides.
 // LDS image of a stage: [A: 64 rows | B: 64 rows] x 128 bytes; one DMA instruction fills 8 rows; slot s of row r
@@ -864,17 +696,14 @@ gram_ring_kernel(GramArgs args) {
     static_assert(NST == 3 || NST == 5, "ring of 3 or 5 stages");
     extern __shared__ v2d smem[];  // [NST stages][A | B]
     // Outside the stage loop a wave runs at raised priority: next to waves that keep the matrix pipe full, a wave
-    // at equal priority is granted about one instruction per MFMA (27 ns) whatever its type -- the timeline build
-    // shows 10-26 us for the few hundred scalar instructions that find the tile, and as much for the epilogue,
+    // at equal priority is granted about one instruction per MFMA (27 ns) whatever its type -- round 2's timeline build
+    // showed 10-26 us for the few hundred scalar instructions that find the tile, and as much for the epilogue,
     // during which the workgroup's LDS ring sits idle.
     __builtin_amdgcn_s_setprio(3);
-    [[maybe_unused]] const uint64_t t_start = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
-    [[maybe_unused]] uint64_t t_first = 0;
     GramJobDev J;
     int ti, tj;
     if (!gram_locate(args, (int64_t)blockIdx.x, J, ti, tj)) return;
     const bool sym = (J.flags & QK_GRAM_SYMMETRIC) != 0;
-    [[maybe_unused]] const uint64_t t_located = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -947,7 +776,6 @@ gram_ring_kernel(GramArgs args) {
     for (int s = 0; s < NST - 1; ++s)
 #pragma unroll
         for (int e = 0; e < NE; ++e) dma(s, (uint32_t)min(s, lastst) * 128u, e);
-    [[maybe_unused]] const uint64_t t_issued = (QK_GRAM_ABLATE & 128) ? wall_clock64() : 0;
 
     const int frag_k = lane >> 4, frag_r = lane & 15;
     typedef const __attribute__((address_space(3))) v2d* lfrag_t;
@@ -973,7 +801,7 @@ gram_ring_kernel(GramArgs args) {
     // any more: branch-free and harmless.
     auto stage = [&](auto s_c, int hh) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value;
-        const uint32_t koff = (QK_GRAM_ABLATE & 8) ? 0u : (uint32_t)min(hh + NST - 1, lastst) * 128u;
+        const uint32_t koff = (uint32_t)min(hh + NST - 1, lastst) * 128u;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             double sa[TM], db[TN];
@@ -1015,7 +843,6 @@ gram_ring_kernel(GramArgs args) {
     using std::integral_constant;
     const int meet_mask = (1 << args.sync_shift) - 1;
     wait_next_stage();   // here: stage 0
-    if constexpr ((QK_GRAM_ABLATE & 128) != 0) t_first = wall_clock64();
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -1044,20 +871,6 @@ gram_ring_kernel(GramArgs args) {
     }
     __builtin_amdgcn_s_setprio(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be writing this workgroup's LDS when it ends
-    if constexpr ((QK_GRAM_ABLATE & 128) != 0) {   // timeline build, as in gram_lean_kernel
-        const uint64_t t_loop = wall_clock64();
-        gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
-        __builtin_amdgcn_s_waitcnt(0);
-        const uint64_t t_end = wall_clock64();
-        if (tid == 0 && args.trace) {
-            double* o = args.trace + (int64_t)blockIdx.x * 8;
-            o[0] = (double)t_start; o[1] = (double)t_first; o[2] = (double)t_loop; o[3] = (double)t_end;
-            o[4] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-            o[5] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-            o[6] = (double)t_located; o[7] = (double)t_issued;   // (the lean kernel leaves ti, tj here)
-        }
-        return;
-    }
     gram_epilogue<TM, TN, true>(acc, J, row0 + wm * (TM * 16), col0 + wn * (TN * 16), lane, sym);
 }
 
@@ -1488,48 +1301,25 @@ void launch_dma_variant(const GramArgs& args, unsigned blocks, hipStream_t strea
             (const void*)gram_dma_kernel<WM, WN, TM, TN, K3M>, launch_dma_variant<WM, WN, TM, TN, K3M>     \
     }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int SCHED>
-void launch_lean_variant(const GramArgs& args, unsigned blocks, hipStream_t stream) {
-    using C = GramDmaCfg<WAVES_M, WAVES_N, TM, TN, true>;
-    hipLaunchKernelGGL((gram_lean_kernel<WAVES_M, WAVES_N, TM, TN, SCHED>), dim3(blocks), dim3(C::THREADS), C::LDS_BYTES,
-                       stream, args);
-}
-
-#define QK_LEAN_VARIANT(NAME, WM, WN, TM, TN, SCHED, LR, LC)                                               \
-    Variant {                                                                                              \
-        NAME, GramDmaCfg<WM, WN, TM, TN, true>::BM, GramDmaCfg<WM, WN, TM, TN, true>::BN,                  \
-            GramDmaCfg<WM, WN, TM, TN, true>::THREADS, 16, LR, LC, GramDmaCfg<WM, WN, TM, TN, true>::LDS_BYTES, \
-            (const void*)gram_lean_kernel<WM, WN, TM, TN, SCHED>, launch_lean_variant<WM, WN, TM, TN, SCHED> \
-    }
-
 template <int NST>
 void launch_ring_variant(const GramArgs& args, unsigned blocks, hipStream_t stream) {
     hipLaunchKernelGGL((gram_ring_kernel<NST>), dim3(blocks), dim3(256), NST * 128 * 128, stream, args);
 }
 
 static const Variant kVariants[] = {
-    QK_VARIANT("4m_128x128_w8_bk8", 2, 4, 4, 2, 8, false),
-    QK_VARIANT("4m_128x128_w8_bk16", 2, 4, 4, 2, 16, false),
-    QK_DMA_VARIANT("dma3m_128x128_w8", 2, 4, 4, 2, true, 2, 3),
-    QK_DMA_VARIANT("dma4m_128x128_w8", 2, 4, 4, 2, false, 2, 3),
-    QK_DMA_VARIANT("dma3m_64x64_w4", 2, 2, 2, 2, true, 2, 3),    // two independent workgroups per CU
-    QK_DMA_VARIANT("dma3m_64x64_w4_g64", 2, 2, 2, 2, true, 3, 3),  // ... whose 64 tiles per XCD form ONE 8 x 8 group
-    QK_DMA_VARIANT("dma3m_64x64_w4_g4x16", 2, 2, 2, 2, true, 2, 4),
-    QK_LEAN_VARIANT("lean3m_64x64_w4", 2, 2, 2, 2, 0, 3, 3),      // the round-1 geometry with the lean inner loop
+    QK_VARIANT("4m_128x128_w8_bk8", 2, 4, 4, 2, 8, false),          // under 3 qubits (rows shorter than a DMA stage)
+    QK_DMA_VARIANT("dma3m_64x64_w4_g64", 2, 2, 2, 2, true, 3, 3),   // rows beyond 2^22 amplitudes (64-bit addressing)
     Variant{"ring3_64x64_w4", 64, 64, 256, 8, 3, 3, 3 * 128 * 128, (const void*)gram_ring_kernel<3>, launch_ring_variant<3>},   // three workgroups per CU
     Variant{"ring5_64x64_w4", 64, 64, 256, 8, 3, 3, 5 * 128 * 128, (const void*)gram_ring_kernel<5>, launch_ring_variant<5>},   // two per CU, four stages of prefetch
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // Default, from in-process A/B runs (tools/gram_ab.py): the ring kernels, three stages and three
 // workgroups per CU for rows of up to 1024 amplitudes, five stages and two workgroups per CU above.  All variants
-// give bitwise identical results (same tiles, same summation order).  dma3m_64x64_w4_g64 was the round-1 default
-// and serves rows beyond 2^22 amplitudes, where the 32-bit lane offsets of the lean and ring kernels end.
-constexpr int kRing3Variant = 8, kRing5Variant = 9;
-constexpr int kFallbackVariant = 5;
+// give bitwise identical results (same tiles, same summation order).
+constexpr int kSmallVariant = 0, kFallbackVariant = 1, kRing3Variant = 2, kRing5Variant = 3;
 
 static std::atomic<int> g_variant{-1};       // forced by QK_GRAM_VARIANT / qk_gram_set_variant; -1 = the default
 static std::atomic<bool> g_env_read{false};
-static std::atomic<double*> g_trace{nullptr};  // timeline builds only
 static DeviceOnce g_attr_set[kNumVariants];
 
 static int pick_variant(const qk_gram_job* jobs, int n_jobs, int64_t D) {
@@ -1564,16 +1354,14 @@ extern "C" int qk_gram_set_variant(const char* name) {
     return fail(QK_ERR_INVALID, "qk_gram_set_variant: unknown variant");
 }
 
-// timeline builds (QK_GRAM_ABLATE & 128) only: device table of 8 doubles per workgroup of the next launches
-extern "C" void qk_gram_set_trace(double* table_dev) { qk::g_trace = table_dev; }
-
 extern "C" const char* qk_gram_variant_for(int64_t rows, int64_t D) {
     using namespace qk;
     qk_gram_job j;
     std::memset(&j, 0, sizeof(j));
     j.ma = j.nb = rows;
     int vi = pick_variant(&j, 1, D);
-    if (D < kVariants[vi].min_d) vi = 0;
+    if (D < kVariants[vi].min_d) vi = kSmallVariant;
+    if (D > ((int64_t)1 << 22) && vi >= kRing3Variant) vi = kFallbackVariant;
     return kVariants[vi].name;
 }
 
@@ -1639,9 +1427,8 @@ static int build_gram_args(const qk_gram_job* jobs, int n_jobs, int64_t D, int b
 extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
     using namespace qk;
     int vi = pick_variant(jobs, n_jobs, D);
-    if (D < kVariants[vi].min_d) vi = 0;  // LDS-DMA tiles need 16 amplitudes per k-tile; tiny circuits use variant 0
-    if (D > ((int64_t)1 << 22) && (std::strncmp(kVariants[vi].name, "lean", 4) == 0 || std::strncmp(kVariants[vi].name, "ring", 4) == 0))
-        vi = kFallbackVariant;  // 32-bit lane offsets
+    if (D < kVariants[vi].min_d) vi = kSmallVariant;   // a DMA stage is 8 amplitudes (16 for the fallback kernel)
+    if (D > ((int64_t)1 << 22) && vi >= kRing3Variant) vi = kFallbackVariant;   // 32-bit lane offsets of the rings
     const Variant& V = kVariants[vi];
     GramArgs args;
     int64_t blocks = 0;
@@ -1652,7 +1439,6 @@ extern "C" int qk_gram_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, 
         QK_HIP(hipFuncSetAttribute(V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds));
         g_attr_set[vi].done();
     }
-    if (QK_GRAM_ABLATE & 128) args.trace = g_trace.load();
     // Pacing counters of the ring kernel (see gram_ring_kernel): one per cohort of 32 workgroups, cleared in stream
     // order before the launch.  The table is one static array per device, handed out as a ring: every launch takes
     // the next slice of it (a ticket drawn here, under a mutex, in the order the host enqueues), so launches that
@@ -1729,7 +1515,6 @@ static int launch_gram32_ring(const qk_gram_job* jobs, int n_jobs, int64_t D, hi
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
-static std::atomic<int> g_tile32{0};   // 0 = choose per call, 64 / 128 = forced (QK_GRAM32_TILE, A/B runs)
 }  // namespace qk
 
 extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D, void* stream) {
@@ -1752,14 +1537,8 @@ extern "C" int qk_gram32_jobs_dev(const qk_gram_job* jobs, int n_jobs, int64_t D
         QK_HIP(hipGetLastError());
         return QK_OK;
     }
-    static std::atomic<bool> env_read{false};
-    if (!env_read.exchange(true)) {
-        if (const char* e = std::getenv("QK_GRAM32_TILE")) g_tile32 = std::atoi(e);
-    }
-    // QK_GRAM32_TILE=64 / 128: the round-1 kernels (A/B runs); default: the ring kernels, as in FP64
-    const int forced = g_tile32.load();
-    if (forced == 128) return launch_gram32<2, 4, 4, 2>(jobs, n_jobs, D, (hipStream_t)stream);
-    if (forced == 64 || D > ((int64_t)1 << 22)) return launch_gram32<2, 2, 2, 2>(jobs, n_jobs, D, (hipStream_t)stream);
+    // the ring kernels, as in FP64; rows beyond 2^22 amplitudes: the double-buffered kernel with 64-bit addressing
+    if (D > ((int64_t)1 << 22)) return launch_gram32<2, 2, 2, 2>(jobs, n_jobs, D, (hipStream_t)stream);
     return D <= 1024 ? launch_gram32_ring<3>(jobs, n_jobs, D, (hipStream_t)stream)
                      : launch_gram32_ring<5>(jobs, n_jobs, D, (hipStream_t)stream);
 }

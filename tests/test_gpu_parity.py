@@ -474,8 +474,8 @@ def test_gram_raw_layout_asymmetric():
 
 def test_gram_kernel_variants_agree_bitwise():
     """Every Gram kernel sums the amplitudes of an entry in the same order (16 x 16 x 4 MFMA steps in ascending
-    k, three accumulators), so the round-1 kernel, the lean one and both LDS-ring kernels must give the SAME
-    bits -- on ragged edges, cross jobs with the transposed copy, symmetric jobs, one-stage rows (D = 8) and rows
+    k, three accumulators), so the double-buffered kernel that serves rows beyond 2^22 amplitudes and both
+    LDS-ring kernels must give the SAME bits -- on ragged edges, cross jobs with the transposed copy, symmetric jobs, one-stage rows (D = 8) and rows
     whose stage count leaves every remainder of the ring's unrolling."""
     import ctypes as C
     import torch
@@ -484,7 +484,7 @@ def test_gram_kernel_variants_agree_bitwise():
     lib = _lib.load()
     lib.qk_gram_set_variant.argtypes = [C.c_char_p]
     lib.qk_gram_set_variant.restype = C.c_int
-    names = ["dma3m_64x64_w4_g64", "lean3m_64x64_w4", "ring3_64x64_w4", "ring5_64x64_w4"]
+    names = ["dma3m_64x64_w4_g64", "ring3_64x64_w4", "ring5_64x64_w4"]
     rng = np.random.default_rng(78)
     try:
         # the last case has more tiles (864 + 528) than the chip has slots and a ragged last round in both jobs

@@ -5,9 +5,6 @@ import argparse, ctypes as C, json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quake_amd import _lib
-if os.environ.get("QK_ABL"):   # another build of the library under tools/_abl (tools/gram_ablate.sh), e.g. an older one for a same-box A/B
-    from pathlib import Path
-    _lib.LIB_PATH = Path(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) / "tools" / "_abl" / ("libquake_hip_abl%s.so" % os.environ["QK_ABL"])
 from quake_amd import device as qdev, featuremaps as fm
 from quake_amd.circuit import ParameterVector
 

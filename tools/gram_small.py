@@ -4,9 +4,6 @@ import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quake_amd import _lib
-if os.environ.get("QK_ABL"):   # an ablation build from tools/gram_ablate.sh
-    from pathlib import Path
-    _lib.LIB_PATH = Path(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) / "tools" / "_abl" / ("libquake_hip_abl%s.so" % os.environ["QK_ABL"])
 from quake_amd import device as qdev
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 D = 1 << n

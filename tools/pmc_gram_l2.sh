@@ -5,7 +5,7 @@ N=$1; q=$2; out=gpurun_out/$3; ctr=${4:-"TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TC
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-V="dma3m_64x64_w4_g64 lean3m_64x64_w4 ring5_64x64_w4"
+V="dma3m_64x64_w4_g64 ring5_64x64_w4"
 timeout -s KILL 250 rocprofv3 --pmc $ctr --kernel-trace -d $R/$out/pL -o p --output-format csv -- python3 $R/tools/gram_ab.py --rows $N --qubits $q --rounds 1 $V > $R/$out/l.log 2>&1 || { tail -5 $R/$out/l.log; exit 1; }
 cd $R
 python3 - <<PY

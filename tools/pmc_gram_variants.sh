@@ -5,7 +5,7 @@ N=$1; q=$2; out=gpurun_out/$3
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-V="dma3m_64x64_w4_g64 lean3m_64x64_w4 ring3_64x64_w4 ring5_64x64_w4"
+V="dma3m_64x64_w4_g64 ring3_64x64_w4 ring5_64x64_w4"
 timeout -s KILL 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/$out/pA -o p --output-format csv -- python3 $R/tools/gram_ab.py --rows $N --qubits $q --rounds 1 $V > $R/$out/a.log 2>&1 || exit 1
 timeout -s KILL 250 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $R/$out/pB -o p --output-format csv -- python3 $R/tools/gram_ab.py --rows $N --qubits $q --rounds 1 $V > $R/$out/b.log 2>&1 || exit 1
 cd $R
