@@ -13,6 +13,7 @@
 //   3. splits the stage list into passes whose non-diagonal gates only touch
 //      "local" qubits (<= 13, the part of the state one workgroup keeps in LDS).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -601,9 +602,13 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         c.passes.push_back(ps);
     }
 
-    // ---- 4. the register-resident program (10 to 13 qubits, one pass, every qubit local: qk_reg.h) ----------
+    // ---- 4. the register-resident program (one pass, every qubit local: qk_reg.h) ------------------------------
+    // 10 to 13 qubits: one sample per workgroup.  4 to 9 qubits: 2^(Lv - n) samples per workgroup side by side in a
+    // "virtual" register of Lv = 10 .. 12 index bits whose top bits number the sample -- they are thread bits in every
+    // layout and no gate touches them, so one instruction stream (segments, ops, transposes) serves all those samples
+    // and only the angles, matrices and phase tables exist once per sample.
     c.reg_blob.clear();
-    if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1 && c.passes[0].L == n) {
+    auto plan_reg = [&](const int Lv, const size_t lds_limit) -> bool {
         // Single-qubit gates on distinct qubits with nothing between them commute: inside such a run the gates are
         // taken in ascending qubit order, so that a layer of gates fills whole groups of four neighbouring qubits and
         // the groups with the low qubits come first (the last layout then keeps the low qubits in the thread index:
@@ -623,7 +628,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         // (QK_REG_RB=3 selects the 8-amplitude form for A/B runs; it is not the default: at 128 registers the compiler
         // still spills a few values, and a scratch access would break the kernel's counted memory waits)
         static const int rb_env = std::getenv("QK_REG_RB") ? std::atoi(std::getenv("QK_REG_RB")) : 0;
-        const int RB = rb_env == 3 ? 3 : 4;
+        const int RB = (rb_env == 3 && Lv == n) ? 3 : 4;
+        const int n_samp = 1 << (Lv - n);      // samples per workgroup
         struct SegDraft { std::vector<int> bits, ids; };
         std::vector<SegDraft> sd(1);
         for (int id : order) {
@@ -652,7 +658,11 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         std::vector<RegSeg> segs;
         std::vector<RegOp> rops;
         std::vector<RegTab> tabs;
-        std::vector<RegTerm> rterms;
+        std::vector<RegTerm> rterms;      // terms the simulator evaluates per thread (between two thread bits, or a register and a thread bit)
+        struct TabTerm { int type, va, vb, tag; };
+        std::vector<TabTerm> tterms;      // terms that live in a phase table (reg_table_kernel)
+        constexpr int kNoDst = 0x7fffffff;   // DevExpr::dst of an angle only the table kernel reads (DevExpr::gate = its tterm)
+        int n_itab = 0;
         std::vector<DevExpr> rexprs;
         std::vector<DevMat> rmats;
         std::vector<DevComp> rcomps;
@@ -704,17 +714,20 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             auto rpos = [&](int q) { return (int)(std::find(g.bits.begin(), g.bits.end(), q) - g.bits.begin()); };
             for (int q = 0; q < n; ++q)
                 if (rpos(q) == RB) tb.push_back(q);
-            {   // deposit runs: thread bit j -> qubit tb[j]; maximal runs with a constant shift
+            {   // deposit runs: thread bit j -> qubit tb[j], the sample bits above them -> index bits n .. Lv - 1;
+                // maximal runs with a constant shift
+                std::vector<int> dep = tb;
+                for (int q = n; q < Lv; ++q) dep.push_back(q);
                 sg.nrun = 0;
-                for (size_t j = 0; j < tb.size();) {
-                    const int sh = tb[j] - (int)j;
+                for (size_t j = 0; j < dep.size();) {
+                    const int sh = dep[j] - (int)j;
                     uint32_t mask = 0;
-                    while (j < tb.size() && tb[j] - (int)j == sh) mask |= 1u << j, ++j;
+                    while (j < dep.size() && dep[j] - (int)j == sh) mask |= 1u << j, ++j;
                     sg.run[sg.nrun++] = mask | ((uint32_t)sh << 16);
                 }
             }
-            lo.assign(tb.begin(), tb.begin() + 4);
-            hi.assign(tb.begin() + 4, tb.end());
+            lo.assign(tb.begin(), tb.begin() + std::min<size_t>(4, tb.size()));
+            hi.assign(tb.begin() + lo.size(), tb.end());
             auto in = [](const std::vector<int>& v, int q) { return std::find(v.begin(), v.end(), q) != v.end(); };
             // three tables (four when the thread has nine bits): register bits, low thread bits, high thread bits
             // three tables: register bits, low thread bits, high thread bits -- the last one in 2^(extra) slots of 16
@@ -724,7 +737,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 table(g.bits, 0, 0u, tA, nA);
                 table(lo, 0, 0u, tL, nL);
                 const int extra = std::max(0, (int)hi.size() - 4);
-                for (int x = 0; x < (1 << extra); ++x) {
+                for (int x = 0; x < (1 << extra) && !hi.empty(); ++x) {     // (no high thread qubits: no third table)
                     uint32_t fixed = 0;
                     for (int b = 0; b < extra; ++b)
                         if ((x >> b) & 1) fixed |= 1u << hi[4 + b];
@@ -740,6 +753,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 op.kind = RG_INIT;
                 op.flags = all_h ? 1 : 0;
                 op.tab = tables(0, -1, 0, -1, (int)extra_mask, -1);   // nt < 0: first-column products; t0 = mask of the extra qubits (values: fixed)
+                n_itab = (int)tabs.size();
                 rops.push_back(op);
             }
             for (int id : g.ids) {
@@ -759,8 +773,20 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                         else k = 3;
                         cls[k].push_back(t);
                     }
-                    int start[6];
-                    for (int k = 0; k < 5; ++k) {
+                    int tstart[4];      // RR, lo, hi -> table terms
+                    for (int k = 0; k < 3; ++k) {
+                        tstart[k] = (int)tterms.size();
+                        for (const Item& t : cls[k]) {
+                            tterms.push_back(TabTerm{t.kind, t.q0, t.q1 >= 0 ? t.q1 : 0, -1});
+                            if (t.expr >= 0) {
+                                tterms.back().tag = (int)tterms.size() - 1;
+                                r_expr(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, kNoDst, (int)tterms.size() - 1);
+                            }
+                        }
+                    }
+                    tstart[3] = (int)tterms.size();
+                    int start[6] = {0, 0, 0, 0, 0, 0};      // TX, RT -> evaluated per thread
+                    for (int k = 3; k < 5; ++k) {
                         start[k] = (int)rterms.size();
                         for (const Item& t : cls[k]) {
                             RegTerm rt{};
@@ -781,7 +807,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                     // directly behind the product state of an all-Hadamard first layer every amplitude is still the constant
                     // held in the running scale: the stage writes its phases instead of multiplying by them
                     if (!rops.empty() && (int)rops.size() == sg.op0 + 1 && rops.back().kind == RG_INIT && (rops.back().flags & 1)) op.flags |= 256;
-                    op.tab = tables(start[0], start[1] - start[0], start[1], start[2] - start[1], start[2], start[3] - start[2]);
+                    op.tab = tables(tstart[0], tstart[1] - tstart[0], tstart[1], tstart[2] - tstart[1], tstart[2], tstart[3] - tstart[2]) - n_itab;
                     op.t0 = start[3];
                     op.nTX = start[4] - start[3];
                     op.nRT = start[5] - start[4];
@@ -816,31 +842,70 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             sg.op1 = (int)rops.size();
             segs.push_back(sg);
         }
+        // angle programs the simulator itself reads first (terms per thread, matrices), those of the table kernel behind
+        // them; inside each part programs of one shape side by side (as for the LDS kernel's pre-pass: uniform control flow)
+        auto shape = [&](const DevExpr& e) {
+            uint64_t hsh = 1469598103934665603ull;
+            for (int k = 0; k < e.len; ++k) hsh = (hsh ^ (uint64_t)(c.prog[e.start + k].op + 1)) * 1099511628211ull;
+            return hsh ^ (uint64_t)e.len;
+        };
+        std::stable_sort(rexprs.begin(), rexprs.end(), [&](const DevExpr& x, const DevExpr& y) {
+            if ((x.dst == kNoDst) != (y.dst == kNoDst)) return y.dst == kNoDst;
+            if (x.len != y.len) return x.len > y.len;
+            return shape(x) < shape(y);
+        });
+        size_t n_expr_k = 0;
+        for (size_t e = 0; e < rexprs.size(); ++e) {
+            if (rexprs[e].dst == kNoDst) tterms[rexprs[e].gate].tag = (int)e;      // where the term finds its (cos, sin)
+            else n_expr_k = e + 1;
+        }
+        // the table kernel's records: which entries of a table take a term's factor, which its conjugate
+        std::vector<RegTabTerm> tts;
+        for (size_t ti = (size_t)n_itab; ti < tabs.size(); ++ti) {
+            RegTab& tb = tabs[ti];
+            const int first = (int)tts.size();
+            for (int k = 0; k < tb.nt; ++k) {
+                const TabTerm& t = tterms[tb.t0 + k];
+                RegTabTerm r{t.type == TM_CZ ? -1 : t.tag, 0u};
+                for (uint32_t x = 0; x < (1u << tb.nbits); ++x) {
+                    uint32_t w = tb.fixed;
+                    for (int b = 0; b < tb.nbits; ++b) w |= ((x >> b) & 1u) << tb.bits[b];
+                    const uint32_t ba = (w >> t.va) & 1u, bb = (w >> t.vb) & 1u;
+                    const bool on = t.type == TM_RZ || (t.type == TM_P ? ba != 0u : (t.type == TM_CZ ? (ba & bb) != 0u : (ba ^ bb) != 0u));
+                    if (on) r.masks |= 1u << x;
+                    if (t.type == TM_RZ && !ba) r.masks |= 1u << (16 + x);
+                }
+                tts.push_back(r);
+            }
+            tb.t0 = first;
+        }
         const bool fits = (int)tabs.size() <= kRegMaxTabs && (int)rterms.size() <= kRegMaxTerms && (int)rmats.size() <= std::min(kRegMaxMats, 255);
-        const size_t lds = ((size_t)16 << n) + 32 * rterms.size() + 64 * rmats.size() + (256 + 32) * tabs.size() + 16 * rcomps.size() +
-                           8 * rexprs.size() + 4 * rfacts.size() + 4 * (size_t)n + 64 +
-                           (size_t)32 * ((rexprs.size() + 63) / 64 * 64);   // two angle buffers, slots of 64 pairs
-        const size_t waves = std::max<size_t>(1, ((size_t)1 << (n - RB)) / 64);
-        const size_t nd = ((rexprs.size() + 63) / 64 + waves - 1) / waves;    // angle fetches per wave and sample: at most 4 (counted waits)
-        if (fits && nd <= 4 && lds <= (size_t)160 * 1024) {
-            // angle programs of one shape side by side (as for the LDS kernel's pre-pass): uniform control flow per wave
-            auto shape = [&](const DevExpr& e) {
-                uint64_t hsh = 1469598103934665603ull;
-                for (int k = 0; k < e.len; ++k) hsh = (hsh ^ (uint64_t)(c.prog[e.start + k].op + 1)) * 1099511628211ull;
-                return hsh ^ (uint64_t)e.len;
-            };
-            std::stable_sort(rexprs.begin(), rexprs.end(), [&](const DevExpr& x, const DevExpr& y) {
-                if (x.len != y.len) return x.len > y.len;
-                return shape(x) < shape(y);
-            });
+        // LDS: the transpose image; per sample: terms, matrices, product-state tables (unless all-Hadamard) and two buffers
+        // of stage tables; the staged records; two angle buffers
+        const size_t n_dtab = tabs.size() - (size_t)n_itab, n_itab_built = all_h ? 0 : (size_t)n_itab;
+        const size_t n_slot = ((size_t)n_samp * n_expr_k + 63) / 64 * 64;      // slots of 64 (cos, sin) pairs
+        const size_t t_slot = ((size_t)n_samp * n_dtab * 16 + 63) / 64;        // slots of 64 table entries
+        // (the stage tables of the NEXT group arrive while this one computes: two buffers -- one, filled at the top of a
+        // group's turn, when two do not fit even a lone workgroup per CU: deep circuits at 13 qubits)
+        const size_t lds_but_tabs = ((size_t)16 << Lv) + (size_t)n_samp * (32 * rterms.size() + 64 * rmats.size() + 256 * n_itab_built) +
+                           32 * (size_t)n_itab + 16 * rcomps.size() + 8 * n_expr_k + 4 * rfacts.size() + 4 * (size_t)n + 64 + 32 * n_slot;
+        const bool tab_single = lds_but_tabs + 2048 * t_slot > lds_limit && lds_limit >= (size_t)160 * 1024;
+        const size_t lds = lds_but_tabs + (tab_single ? 1024 : 2048) * t_slot;
+        const size_t waves = std::max<size_t>(1, ((size_t)1 << (Lv - RB)) / 64);
+        const size_t nd = (n_slot / 64 + waves - 1) / waves + (t_slot + waves - 1) / waves;    // fetches per wave and sample group (up to 8: counted waits)
+        if (std::getenv("QK_REG_DEBUG")) std::fprintf(stderr, "[reg plan] Lv=%d fits=%d nd=%zu lds=%zu limit=%zu tabs=%zu terms=%zu mats=%zu\n", Lv, (int)fits, nd, lds, lds_limit, tabs.size(), rterms.size(), rmats.size());
+        if (!(fits && nd <= 64 && lds <= lds_limit)) return false;
+        {
             auto pad16 = [](size_t b) { return (b + 15) / 16 * 16; };
             RegHeader H{};
-            H.L = n;
+            H.L = Lv;
+            H.nq = n;
             H.n_seg = (int)segs.size(); H.n_op = (int)rops.size(); H.n_tab = (int)tabs.size(); H.n_term = (int)rterms.size();
             H.n_expr = (int)rexprs.size(); H.n_mat = (int)rmats.size(); H.n_comp = (int)rcomps.size(); H.n_fact = (int)rfacts.size();
-            H.init_h = all_h ? 1 : 0;
+            H.init_h = (all_h ? 1 : 0) | (tab_single ? 2 : 0);
             H.rb = RB;
             H.init_c = std::ldexp((n & 1) ? 0.70710678118654752440 : 1.0, -(n / 2));
+            H.n_itab = n_itab; H.n_tt = (int)tts.size(); H.n_expr_k = (int)n_expr_k;
             size_t off = pad16(sizeof(RegHeader));
             H.off_seg = (int)off;  off = pad16(off + segs.size() * sizeof(RegSeg));
             H.off_op = (int)off;   off = pad16(off + rops.size() * sizeof(RegOp));
@@ -851,6 +916,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             H.off_comp = (int)off; off = pad16(off + rcomps.size() * sizeof(DevComp));
             H.off_fact = (int)off; off = pad16(off + rfacts.size() * sizeof(int32_t));
             H.off_init = (int)off; off = pad16(off + init_mat.size() * sizeof(int32_t));
+            H.off_tt = (int)off;   off = pad16(off + tts.size() * sizeof(RegTabTerm));
             H.bytes = (int)off;
             c.reg_blob.assign(off / 8, 0);
             char* base = (char*)c.reg_blob.data();
@@ -865,10 +931,23 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             put(H.off_comp, rcomps.data(), rcomps.size() * sizeof(DevComp));
             put(H.off_fact, rfacts.data(), rfacts.size() * sizeof(int32_t));
             put(H.off_init, init_mat.data(), init_mat.size() * sizeof(int32_t));
+            put(H.off_tt, tts.data(), tts.size() * sizeof(RegTabTerm));
             c.reg_lds_bytes = lds;
             c.plan_summary += "; register-resident plan: " + std::to_string(segs.size()) + " segments, " + std::to_string(rops.size()) +
-                              " ops, " + std::to_string(tabs.size()) + " tables";
+                              " ops, " + std::to_string(tabs.size()) + " tables, " + std::to_string(n_samp) + " samples per workgroup of " +
+                              std::to_string(1 << (Lv - RB)) + " threads";
         }
+        return true;
+    };
+    if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1 && c.passes[0].L == n) {
+        plan_reg(n, (size_t)160 * 1024);
+    } else if (n >= kRegPackMinQubits && n < kRegMinQubits && c.passes.size() == 1 && c.passes[0].L == n) {
+        // the widest workgroup that leaves room for two per CU, else the narrowest that fits at all; QK_REG_LV forces one (A/B runs)
+        static const int lv_env = std::getenv("QK_REG_LV") ? std::atoi(std::getenv("QK_REG_LV")) : 0;
+        bool done = false;
+        if (lv_env >= kRegMinQubits && lv_env <= kRegPackMaxWidth) done = plan_reg(lv_env, (size_t)160 * 1024);
+        for (int Lv = kRegPackMaxWidth; Lv >= kRegMinQubits && !done; --Lv) done = plan_reg(Lv, (size_t)80 * 1024);
+        for (int Lv = kRegMinQubits; Lv <= kRegPackMaxWidth && !done; ++Lv) done = plan_reg(Lv, (size_t)160 * 1024);
     }
     return QK_OK;
 }

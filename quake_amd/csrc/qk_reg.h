@@ -13,6 +13,8 @@
 namespace qk {
 
 constexpr int kRegMinQubits = 10;     // 64 threads x 16 amplitudes
+constexpr int kRegPackMinQubits = 4;  // narrower circuits: 2^(L - n) samples side by side in a virtual register of L index bits
+constexpr int kRegPackMaxWidth = 12;  // ... of at most 12 (256 threads)
 constexpr int kRegMaxQubits = 13;     // 512 threads x 16 amplitudes = 128 KiB of LDS for the transposes
 constexpr int kRegMaxTabs = 96;       // phase tables of 16 entries (256 bytes each) per sample
 constexpr int kRegMaxTerms = 256;
@@ -52,8 +54,15 @@ struct RegTab {       // 32 bytes: one table of 16 entries; entry x covers the i
     int32_t bits[4];
     int32_t nbits;
     uint32_t fixed;
-    int32_t t0, nt;   // product over terms [t0, t0 + nt); nt < 0: product of the first columns of the qubits in `bits`
-                      // and of the qubits in the mask t0 (whose values `fixed` holds)
+    int32_t t0, nt;   // tables of the product state (built inside the simulator, from the sample's matrices): nt < 0, product
+                      // of the first columns of the qubits in `bits` and of the qubits in the mask t0 (whose values `fixed`
+                      // holds).  Tables of a diagonal stage (built by reg_table_kernel before the simulator runs and
+                      // fetched by LDS-DMA): product over the RegTabTerm records [t0, t0 + nt)
+};
+
+struct RegTabTerm {   // 8 bytes: one diagonal term's part in one table
+    int32_t expr;     // angle program whose (cos, sin) is the factor; < 0: the constant -1 (cz)
+    uint32_t masks;   // bit x: entry x takes the factor; bit 16 + x: ... its conjugate (rz with the bit clear)
 };
 
 struct RegTerm {      // static part of a diagonal term
@@ -63,10 +72,17 @@ struct RegTerm {      // static part of a diagonal term
 };
 
 struct RegHeader {    // at offset 0 of the blob; off_* are byte offsets from its start (16-byte aligned sections)
-    int32_t L, n_seg, n_op, n_tab, n_term, n_expr, n_mat, n_comp, n_fact, init_h;
+    int32_t L, n_seg, n_op, n_tab, n_term, n_expr, n_mat, n_comp, n_fact;
+    int32_t init_h;   // bit 0: every first gate is a Hadamard; bit 1: ONE buffer of stage tables in LDS instead of two
     int32_t off_seg, off_op, off_tab, off_term, off_expr, off_mat, off_comp, off_fact, off_init, bytes;
-    int32_t rb, pad;  // register qubits per layout: 4 (16 amplitudes per thread) or 3 (8 per thread, twice the threads)
-    double init_c;    // 2^(-L/2): the product state of an all-Hadamard first layer
+    int32_t rb, nq;   // register qubits per layout: 4 (16 amplitudes per thread) or 3 (8 per thread, twice the threads);
+                      // nq = qubits of the circuit: below L when 2^(L - nq) samples share a workgroup (index bits nq .. L - 1
+                      // = the sample; those plans have rb = 4, no table for high thread qubits unless nq > 8)
+    double init_c;    // 2^(-nq/2): the product state of an all-Hadamard first layer
+    // tables [0, n_itab) belong to the product state (built in the simulator unless init_h), [n_itab, n_tab) to the diagonal
+    // stages (RegOp::tab of a DIAG op counts from n_itab); n_tt RegTabTerm records at off_tt
+    int32_t n_itab, n_tt, off_tt;
+    int32_t n_expr_k; // the first n_expr_k angle programs are the ones the simulator reads (the rest: table terms only)
 };
 
 }  // namespace qk

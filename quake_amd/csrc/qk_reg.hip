@@ -12,6 +12,13 @@
 // barrier per transpose is enough.  The LDS image is XOR-swizzled (slot = i ^ (i >> 4 & 15) ^ (i >> 8 & 15) ^ (i >> 12)):
 // linear over the index bits, so a thread's slot is (its own part) ^ (a scalar per register), and the 8 (writes) or 16
 // (reads) lanes that the LDS serves together hit distinct 16-byte slots whichever aligned group of four is in registers.
+//
+// Circuits of 4 to 9 qubits (PACK): 2^(L - nq) samples share a workgroup, side by side in a virtual register of L = 10 .. 12
+// index bits whose top bits number the sample.  Those bits are thread bits in every layout and no gate touches them:
+// segments, ops, transposes and stores are the same instruction stream as for one wide sample, and the per-sample
+// cost of that stream (record loads, dispatch, barriers, loop control -- most of what a narrow circuit pays in the
+// wave-resident and LDS kernels) is shared by all samples of the group.  What differs per sample -- angles, matrices,
+// phase tables -- lives in LDS once per sample and is read at a per-lane offset; matrices stay in vector registers.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -29,6 +36,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));   // native vector: stay
 struct RegArgs {
     const char* blob;      // RegHeader + tables (device)
     const double2* cs;     // (cos, sin) of every angle program, [expr][sample]
+    const double2* tabs;   // phase tables of the diagonal stages, [sample, padded to whole groups][table][16] (reg_table_kernel)
     int64_t N;
     double2* psi;
     float2* psi32;         // FP32 output: the state is evolved in FP64 and rounded once, at the store
@@ -113,7 +121,7 @@ __device__ __forceinline__ void scatter_angle(int dst, int gate, double cn, doub
 // a 2x2 matrix on register position P: eight butterflies between registers k and k | (1 << P).  form: 0 real matrix
 // (x, ry), 1 real diagonal + imaginary off-diagonal (rx), 2 general (sx, composites), 3 hadamard (adds only; its
 // 1 / sqrt 2 goes to the running scale).  e0 .. e3: the matrix as it came out of LDS (not read for a hadamard).
-template <int P, int NA>
+template <int P, int NA, bool PACK>
 __device__ __forceinline__ void u1_reg(v2d (&v)[NA], v2d e0, v2d e1, v2d e2, v2d e3, int form, double& scale) {
     if constexpr ((1 << P) >= NA) return;
     if (form == 3) {
@@ -127,8 +135,10 @@ __device__ __forceinline__ void u1_reg(v2d (&v)[NA], v2d e0, v2d e1, v2d e2, v2d
         scale *= 0.70710678118654752440;
         return;
     }
-    const double m0x = uniform_f64(e0.x), m0y = uniform_f64(e0.y), m1x = uniform_f64(e1.x), m1y = uniform_f64(e1.y);
-    const double m2x = uniform_f64(e2.x), m2y = uniform_f64(e2.y), m3x = uniform_f64(e3.x), m3y = uniform_f64(e3.y);
+    // one sample per workgroup: the matrix is wave-uniform and goes to scalar registers; PACK: every lane has its sample's
+    auto un = [](double x) __attribute__((always_inline)) { if constexpr (PACK) return x; else return uniform_f64(x); };
+    const double m0x = un(e0.x), m0y = un(e0.y), m1x = un(e1.x), m1y = un(e1.y);
+    const double m2x = un(e2.x), m2y = un(e2.y), m3x = un(e3.x), m3y = un(e3.y);
     if (form == 0) {
 #pragma unroll
         for (int k = 0; k < NA; ++k)
@@ -203,51 +213,69 @@ __device__ __forceinline__ void ecr_reg(v2d (&v)[NA]) {
 
 // TBN = log2(threads), RB = register qubits per layout (NA = 2^RB amplitudes per thread), L = TBN + RB.
 // RB = 4: two waves per SIMD (256 VGPRs); RB = 3: four (128 VGPRs) -- LDS holds the same number of samples either way.
-template <int TBN, int RB>
+// PACK: 2^(L - nq) samples per workgroup (see the top of the file); nq = L otherwise.
+template <int TBN, int RB, bool PACK>
 __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegArgs a) {
     extern __shared__ double2 lds[];
     constexpr int L = TBN + RB, T = 1 << TBN, NA = 1 << RB;
     const CWords hw = cwords(a.blob);
-    const int n_seg = hw[1], n_tab = hw[3], n_term = hw[4], n_expr = hw[5], n_mat = hw[6], n_comp = hw[7], n_fact = hw[8];
+    const int nq = PACK ? hw[21] : L;                  // qubits of the circuit
+    const int sbits = L - nq, S = 1 << sbits;           // samples per workgroup
+    static_assert(offsetof(RegHeader, nq) == 84, "RegHeader is read word by word");
+    const int n_seg = hw[1], n_term = hw[4], n_mat = hw[6], n_comp = hw[7], n_fact = hw[8], init_h = hw[9];
+    const int n_itab = hw[24], n_dtab = hw[3] - hw[24], n_expr = hw[27];      // n_expr: the angle programs the simulator reads itself
     const int off_seg = hw[10], off_op = hw[11], off_tab = hw[12], off_term = hw[13], off_expr = hw[14], off_mat = hw[15],
               off_comp = hw[16], off_fact = hw[17], off_init = hw[18];
     const double init_c = ((const double*)(a.blob + 88))[0];
-    static_assert(sizeof(RegHeader) == 96 && offsetof(RegHeader, init_c) == 88 && sizeof(RegSeg) == 64, "RegHeader and RegSeg are read word by word");
+    static_assert(sizeof(RegHeader) == 112 && offsetof(RegHeader, init_c) == 88 && offsetof(RegHeader, n_itab) == 96 && offsetof(RegHeader, n_expr_k) == 108 &&
+                      sizeof(RegSeg) == 64, "RegHeader and RegSeg are read word by word");
     // LDS map (32-bit LDS addresses: see ldsr / ldsw): the transpose image, then per-sample terms, matrices and tables,
     // then what is staged once per workgroup, then two buffers of angles
     const uint32_t state_a = (uint32_t)(size_t)(lptr_t)lds;
+    // (per sample: terms, matrices, tables of the product state; then two buffers of stage tables, the staged records, two
+    // buffers of angles)
+    const int n_ib = (init_h & 1) ? 0 : n_itab;      // product-state tables are built here, unless every first gate is a Hadamard
+    const bool tab_single = (init_h & 2) != 0;      // one buffer of stage tables: fetched at the top of the group's own turn
+    const uint32_t rt_s = 32u * (uint32_t)n_term, mat_s = 64u * (uint32_t)n_mat, itab_s = 256u * (uint32_t)n_ib, dtab_s = 256u * (uint32_t)n_dtab;
+    const int t_piece = (S * n_dtab) << 4;                          // 16-byte entries of a group's stage tables
+    const uint32_t dt_bytes = (uint32_t)((t_piece + 63) & ~63) << 4;   // one buffer: whole fetch instructions of 64 entries
     const uint32_t rt_a = state_a + (16u << L);                     // 32 B per term: (cos, sin), type, va, vb, rpos
-    const uint32_t mat_a = rt_a + 32u * (uint32_t)n_term;           // 64 B per matrix
-    const uint32_t tab_a = mat_a + 64u * (uint32_t)n_mat;           // 256 B per table
-    const uint32_t stab_a = tab_a + 256u * (uint32_t)n_tab;         // RegTab records, 32 B
-    const uint32_t comp_a = stab_a + 32u * (uint32_t)n_tab;         // DevComp records, 16 B
+    const uint32_t mat_a = rt_a + rt_s * (uint32_t)S;               // 64 B per matrix
+    const uint32_t itab_a = mat_a + mat_s * (uint32_t)S;            // 256 B per table
+    const uint32_t dtab_a = itab_a + itab_s * (uint32_t)S;
+    const uint32_t stab_a = dtab_a + (tab_single ? 1u : 2u) * dt_bytes;                 // RegTab records of the product-state tables, 32 B
+    const uint32_t comp_a = stab_a + 32u * (uint32_t)n_itab;        // DevComp records, 16 B
     const uint32_t sexpr_a = comp_a + 16u * (uint32_t)n_comp;       // (dst, gate) of every angle program, 8 B
     const uint32_t fact_a = sexpr_a + 8u * (uint32_t)n_expr;
     const uint32_t init_a = fact_a + 4u * (uint32_t)n_fact;
-    const int n_slot = (n_expr + 63) & ~63;                         // one slot of 64 pairs per fetch instruction
-    const uint32_t cs_a = (init_a + 4u * L + 15u) & ~15u;           // two buffers of n_slot (cos, sin) pairs
+    const int n_slot = (n_expr * S + 63) & ~63;                     // one slot of 64 pairs per fetch instruction; pair e * S + s
+    const uint32_t cs_a = (init_a + 4u * (uint32_t)nq + 15u) & ~15u;   // two buffers of n_slot (cos, sin) pairs
     const CWords c_seg = cwords(a.blob + off_seg), c_op = cwords(a.blob + off_op);
     const int tid0 = threadIdx.x;
     if (state_a & ((16u << L) - 1u)) __builtin_trap();      // the swizzled image must start where its address bits are clear (dynamic LDS starts at 0)
 
     // ---- once per workgroup: what does not depend on the sample -----------------------------------------------
-    for (int t = tid0; t < n_term; t += T) {
+    for (int i = tid0; i < n_term * S; i += T) {      // (every sample of the group has its copy: i = t * S + s)
+        const int t = i >> sbits;
         const RegTerm d = ((const RegTerm*)(a.blob + off_term))[t];
-        ldsw<v2d>(rt_a + 32u * t, (v2d){-1.0, 0.0});     // TM_CZ; parametric terms get (cos, sin) per sample
-        ldsw<int4v>(rt_a + 32u * t + 16u, (int4v){d.type, d.va, d.vb, d.rpos});
+        const uint32_t at = rt_a + rt_s * (uint32_t)(i & (S - 1)) + 32u * (uint32_t)t;
+        ldsw<v2d>(at, (v2d){-1.0, 0.0});     // TM_CZ; parametric terms get (cos, sin) per sample
+        ldsw<int4v>(at + 16u, (int4v){d.type, d.va, d.vb, d.rpos});
     }
-    for (int m = tid0; m < n_mat; m += T) {
-        const int gate = ((const DevMat*)(a.blob + off_mat))[m].gate;
+    for (int i = tid0; i < n_mat * S; i += T) {
+        const int m_i = i >> sbits;
+        const int gate = ((const DevMat*)(a.blob + off_mat))[m_i].gate;
         const double r = 0.70710678118654752440;
         v2d m00 = (v2d){0, 0}, m01 = m00, m10 = m00, m11 = m00;
         if (gate == QK_H) { m00 = (v2d){r, 0}; m01 = (v2d){r, 0}; m10 = (v2d){r, 0}; m11 = (v2d){-r, 0}; }
         else if (gate == QK_X) { m01 = (v2d){1, 0}; m10 = (v2d){1, 0}; }
         else if (gate == QK_SX) { m00 = (v2d){0.5, 0.5}; m01 = (v2d){0.5, -0.5}; m10 = (v2d){0.5, -0.5}; m11 = (v2d){0.5, 0.5}; }
-        ldsw<v2d>(mat_a + 64u * m, m00); ldsw<v2d>(mat_a + 64u * m + 16u, m01);
-        ldsw<v2d>(mat_a + 64u * m + 32u, m10); ldsw<v2d>(mat_a + 64u * m + 48u, m11);
+        const uint32_t at = mat_a + mat_s * (uint32_t)(i & (S - 1)) + 64u * (uint32_t)m_i;
+        ldsw<v2d>(at, m00); ldsw<v2d>(at + 16u, m01);
+        ldsw<v2d>(at + 32u, m10); ldsw<v2d>(at + 48u, m11);
     }
-    for (int t = tid0; t < 8 * n_tab; t += T) ldsw<int>(stab_a + 4u * t, ((const int32_t*)(a.blob + off_tab))[t]);
-    for (int q = tid0; q < L; q += T) ldsw<int>(init_a + 4u * q, ((const int32_t*)(a.blob + off_init))[q]);
+    for (int t = tid0; t < 8 * n_itab; t += T) ldsw<int>(stab_a + 4u * t, ((const int32_t*)(a.blob + off_tab))[t]);
+    for (int q = tid0; q < nq; q += T) ldsw<int>(init_a + 4u * q, ((const int32_t*)(a.blob + off_init))[q]);
     for (int e = tid0; e < n_expr; e += T) {
         const DevExpr ex = ((const DevExpr*)(a.blob + off_expr))[e];
         ldsw<int2v>(sexpr_a + 8u * e, (int2v){ex.dst, ex.gate});
@@ -255,29 +283,44 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
     for (int k = tid0; k < 4 * n_comp; k += T) ldsw<int>(comp_a + 4u * k, ((const int32_t*)(a.blob + off_comp))[k]);
     for (int k = tid0; k < n_fact; k += T) ldsw<int>(fact_a + 4u * k, ((const int32_t*)(a.blob + off_fact))[k]);
 
-    const int64_t per_wg = (a.N + gridDim.x - 1) / gridDim.x;
+    // a workgroup walks groups of S consecutive samples (the last group of the batch may be short: its missing samples
+    // repeat sample N - 1 -- same angles, same amplitudes, stored to the same place)
+    const int64_t n_group = (a.N + S - 1) >> sbits;
+    const int64_t per_wg = (n_group + gridDim.x - 1) / gridDim.x;
     const int64_t s_begin = (int64_t)blockIdx.x * per_wg;
-    const int64_t s_end = s_begin + per_wg < a.N ? s_begin + per_wg : a.N;
+    const int64_t s_end = s_begin + per_wg < n_group ? s_begin + per_wg : n_group;
     const int wave_s = uni(tid0 >> 6);
     // The angles of sample `smp` into buffer `buf`: wave w fetches the slots w, w + T/64, ... (64 angles per DMA
     // instruction; lanes past the last angle re-read it).  my_nd = how many instructions that is for this wave: the
     // number of memory operations it has in flight is known where it waits for them.
-    const int my_nd = (n_slot / 64 - wave_s + T / 64 - 1) / (T / 64) > 0 ? (n_slot / 64 - wave_s + T / 64 - 1) / (T / 64) : 0;
-    auto fetch_angles = [&](int64_t smp, int buf, int lane) __attribute__((always_inline)) {
-        for (int j = 0; j < my_nd; ++j) {
+    auto share = [&](int slots) { const int k = (slots - wave_s + T / 64 - 1) / (T / 64); return k > 0 ? k : 0; };
+    const int my_na = share(n_slot / 64), my_nt = share((int)(dt_bytes >> 10));
+    auto fetch_angles = [&](int64_t smp, int buf, int lane) __attribute__((always_inline)) {      // smp: the group
+        for (int j = 0; j < my_na; ++j) {
             const int slot = wave_s + j * (T / 64);
-            const int e = min(slot * 64 + lane, n_expr - 1);
-            const double2* src = a.cs + ((int64_t)e * a.N + smp);
+            const int i = min(slot * 64 + lane, n_expr * S - 1);
+            const int e = i >> sbits;
+            const int64_t one = (smp << sbits) + (i & (S - 1));
+            const double2* src = a.cs + ((int64_t)e * a.N + (one < a.N ? one : a.N - 1));
             const uint32_t dst = cs_a + 16u * (uint32_t)(buf * n_slot + slot * 64);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(size_t)dst, 16, 0, 0);
         }
     };
-    if (n_expr > 0 && s_begin < s_end) fetch_angles(s_begin, 0, tid0 & 63);
+    // the group's stage tables: one contiguous block (the table kernel pads the batch to whole groups)
+    auto fetch_tables = [&](int64_t smp, int buf, int lane) __attribute__((always_inline)) {
+        for (int j = 0; j < my_nt; ++j) {
+            const int slot = wave_s + j * (T / 64);
+            const double2* src = a.tabs + (smp * t_piece + min(slot * 64 + lane, t_piece - 1));
+            const uint32_t dst = dtab_a + (uint32_t)buf * dt_bytes + 1024u * (uint32_t)slot;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(size_t)dst, 16, 0, 0);
+        }
+    };
+    if (s_begin < s_end) { fetch_angles(s_begin, 0, tid0 & 63); fetch_tables(s_begin, 0, tid0 & 63); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
 #ifdef QK_REG_TRACE
-    double tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tr_last = wall_clock64();
 #define QK_RMARK(k) do { if (tid0 == 0) { const uint64_t t_ = wall_clock64(); tr[k] += (double)(t_ - tr_last); tr_last = t_; } } while (0)
 #else
@@ -296,27 +339,44 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
         // complete in order -- a counted wait, so the stores go on draining under this sample's arithmetic (a plain
         // vmcnt(0), which is what a prefetch into registers gets from the compiler, holds the workgroup until the whole
         // statevector of the previous sample has left the chip).
-        if (my_nd > 0) {
+        if (my_na > 8) {
+            // (many narrow samples per group: more fetches than a counted wait is written out for below -- wait for
+            // everything, then fetch; the stores of a group are a small part of its time there)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             fetch_angles(sample + 1 < s_end ? sample + 1 : sample, it ^ 1, tid & 63);
-            if (my_nd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 1) : "memory");
-            else if (my_nd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 2) : "memory");
-            else if (my_nd == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 3) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 4) : "memory");
+        } else {
+            // older than this: the group's angles, then its tables (fetched behind the barrier below, one iteration ago)
+            fetch_angles(sample + 1 < s_end ? sample + 1 : sample, it ^ 1, tid & 63);
+            if (my_na == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+            else if (my_na == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 1) : "memory");
+            else if (my_na == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 2) : "memory");
+            else if (my_na == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 3) : "memory");
+            else if (my_na == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 4) : "memory");
+            else if (my_na == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 5) : "memory");
+            else if (my_na == 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 6) : "memory");
+            else if (my_na == 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 7) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 8) : "memory");
         }
         QK_RMARK(0);
         lds_barrier();      // every wave's share of this sample's angles has landed; the previous sample is done with terms / matrices / tables
-        QK_RMARK(0);
-        for (int e = tid; e < n_expr; e += T) {
-            const v2d cs = ldsr<v2d>(cs_a + 16u * (uint32_t)(it * n_slot + e));
-            const int2v de = ldsr<int2v>(sexpr_a + 8u * e);
-            scatter_angle(de.x, de.y, cs.x, cs.y, rt_a, mat_a);
+        // only now may the next group's tables overwrite the buffer the previous group read in its last segment
+        if (tab_single) { if (sample > s_begin) fetch_tables(sample, 0, tid & 63); }      // (the first group's came before the loop)
+        else fetch_tables(sample + 1 < s_end ? sample + 1 : sample, it ^ 1, tid & 63);
+        QK_RMARK(8);
+        for (int i = tid; i < n_expr * S; i += T) {
+            const v2d cs = ldsr<v2d>(cs_a + 16u * (uint32_t)(it * n_slot + i));
+            const int2v de = ldsr<int2v>(sexpr_a + 8u * (uint32_t)(i >> sbits));
+            const uint32_t so = (uint32_t)(i & (S - 1));
+            scatter_angle(de.x, de.y, cs.x, cs.y, rt_a + rt_s * so, mat_a + mat_s * so);
         }
+        if (tab_single) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's tables, fetched a moment ago
         lds_barrier();
-        QK_RMARK(0);
+        QK_RMARK(9);
         if (n_comp) {       // runs of single-qubit gates on one qubit: one thread multiplies a run's factors
-            for (int k = tid; k < n_comp; k += T) {
-                const int4v cc = ldsr<int4v>(comp_a + 16u * k);       // dst, first, count
-                auto M = [&](int f, int j) { return ldsr<v2d>(mat_a + 64u * (uint32_t)f + 16u * j); };
+            for (int i = tid; i < n_comp * S; i += T) {
+                const int4v cc = ldsr<int4v>(comp_a + 16u * (uint32_t)(i >> sbits));       // dst, first, count
+                const uint32_t mat_i = mat_a + mat_s * (uint32_t)(i & (S - 1));
+                auto M = [&](int f, int j) { return ldsr<v2d>(mat_i + 64u * (uint32_t)f + 16u * j); };
                 const int f0 = ldsr<int>(fact_a + 4u * cc.y);
                 v2d m0 = M(f0, 0), m1 = M(f0, 1), m2 = M(f0, 2), m3 = M(f0, 3);
                 for (int j = 1; j < cc.z; ++j) {     // M <- G M
@@ -326,57 +386,52 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                     const v2d n2 = cmul(g2, m0) + cmul(g3, m2), n3 = cmul(g2, m1) + cmul(g3, m3);
                     m0 = n0; m1 = n1; m2 = n2; m3 = n3;
                 }
-                const uint32_t d = mat_a + 64u * (uint32_t)cc.x;
+                const uint32_t d = mat_i + 64u * (uint32_t)cc.x;
                 ldsw<v2d>(d, m0); ldsw<v2d>(d + 16u, m1); ldsw<v2d>(d + 32u, m2); ldsw<v2d>(d + 48u, m3);
             }
             lds_barrier();
         }
-        QK_RMARK(0);
-        // ---- the phase tables of every diagonal stage (and of the product state), 16 entries each ---------------
-        for (int e = tid; e < 16 * n_tab; e += T) {
-            const uint32_t tb = stab_a + 32u * (uint32_t)(e >> 4);      // bits[4], nbits, fixed, t0, nt
+        QK_RMARK(10);
+        // ---- the tables of the product state, 16 entries each: products of the first columns of the first gates' matrices
+        // (not needed when every first gate is a Hadamard; the tables of the diagonal stages arrive ready-made)
+        // (PACK: a wave builds the tables of the samples wave, wave + T / 64, ... of the group, its lanes over the entries)
+        if (n_ib) {
+        for (int so = PACK ? wave_s : 0; so < S; so += PACK ? T / 64 : 1) {
+        const uint32_t mat_i = mat_a + mat_s * (uint32_t)so, tab_i = itab_a + itab_s * (uint32_t)so;
+        for (int e = PACK ? (tid & 63) : tid; e < 16 * n_ib; e += PACK ? 64 : T) {
+            const uint32_t tb = stab_a + 32u * (uint32_t)(e >> 4);      // bits[4], nbits, fixed, t0 (mask of extra qubits), nt < 0
             const int4v bits = ldsr<int4v>(tb), rest = ldsr<int4v>(tb + 16u);
-            const int nbits = rest.x, t0 = rest.z, nt = rest.w;
+            const int nbits = rest.x, t0 = rest.z;
             const uint32_t x = (uint32_t)e & 15u;
-            const uint32_t w = (uint32_t)rest.y | ((x & 1u) << bits.x) | (((x >> 1) & 1u) << bits.y) | (((x >> 2) & 1u) << bits.z) |
-                               (((x >> 3) & 1u) << bits.w);       // (unused positions of `bits` are 0 and x stays below 2^nbits where it counts)
             v2d f = (v2d){1.0, 0.0};
-            if (nt >= 0) {
-                // four terms per step, two chains: their LDS reads are in flight together
-                v2d f2 = (v2d){1.0, 0.0};
-                int k = 0;
-                for (; k + 3 < nt; k += 4) {
-                    const TermL ta = term_at(rt_a, t0 + k), tb2 = term_at(rt_a, t0 + k + 1), tc = term_at(rt_a, t0 + k + 2), td = term_at(rt_a, t0 + k + 3);
-                    f = cmul(f, term_factor(ta, w));
-                    f2 = cmul(f2, term_factor(tb2, w));
-                    f = cmul(f, term_factor(tc, w));
-                    f2 = cmul(f2, term_factor(td, w));
-                }
-                for (; k < nt; ++k) f = cmul(f, term_factor(term_at(rt_a, t0 + k), w));
-                f = cmul(f, f2);
-            } else {
-                auto column = [&](int q, uint32_t bit) {
-                    const int m = ldsr<int>(init_a + 4u * q);
-                    const v2d u = ldsr<v2d>(mat_a + 64u * (uint32_t)(m < 0 ? 0 : m) + 32u * bit);
-                    return m < 0 ? (v2d){bit ? 0.0 : 1.0, 0.0} : u;
-                };
-                if (nbits > 0) f = cmul(f, column(bits.x, x & 1u));
-                if (nbits > 1) f = cmul(f, column(bits.y, (x >> 1) & 1u));
-                if (nbits > 2) f = cmul(f, column(bits.z, (x >> 2) & 1u));
-                if (nbits > 3) f = cmul(f, column(bits.w, (x >> 3) & 1u));
-                for (uint32_t m = (uint32_t)t0; m; m &= m - 1u) {      // the extra high thread qubits of this slot (their values: fixed)
-                    const int q = __builtin_ctz(m);
-                    f = cmul(f, column(q, ((uint32_t)rest.y >> q) & 1u));
-                }
+            auto column = [&](int q, uint32_t bit) {
+                const int m = ldsr<int>(init_a + 4u * q);
+                const v2d u = ldsr<v2d>(mat_i + 64u * (uint32_t)(m < 0 ? 0 : m) + 32u * bit);
+                return m < 0 ? (v2d){bit ? 0.0 : 1.0, 0.0} : u;
+            };
+            if (nbits > 0) f = cmul(f, column(bits.x, x & 1u));
+            if (nbits > 1) f = cmul(f, column(bits.y, (x >> 1) & 1u));
+            if (nbits > 2) f = cmul(f, column(bits.z, (x >> 2) & 1u));
+            if (nbits > 3) f = cmul(f, column(bits.w, (x >> 3) & 1u));
+            for (uint32_t m = (uint32_t)t0; m; m &= m - 1u) {      // the extra high thread qubits of this slot (their values: fixed)
+                const int q = __builtin_ctz(m);
+                f = cmul(f, column(q, ((uint32_t)rest.y >> q) & 1u));
             }
             if ((int)x >= (1 << nbits)) f = (v2d){1.0, 0.0};
-            ldsw<v2d>(tab_a + 16u * e, f);
+            ldsw<v2d>(tab_i + 16u * e, f);
+        }
+        }
         }
         lds_barrier();
-        QK_RMARK(0);
+        QK_RMARK(11);
 
         v2d v[NA];
         double scale = 1.0;
+        // this lane's sample of the group and where its terms, matrices and tables are
+        const uint32_t sid = PACK ? (uint32_t)tid >> (nq - RB) : 0u;
+        const uint32_t rt_l = PACK ? rt_a + rt_s * sid : rt_a, mat_l = PACK ? mat_a + mat_s * sid : mat_a;
+        const uint32_t itab_l = PACK ? itab_a + itab_s * sid : itab_a, dtab_l = dtab_a + (tab_single ? 0u : (uint32_t)it * dt_bytes) + (PACK ? dtab_s * sid : 0u);
+        const int n_lo = nq - RB < 4 ? nq - RB : 4, n_hi = nq - RB - n_lo;      // thread qubits behind the two thread tables (n_hi > 4: second slot)
         for (int sg = 0; sg < n_seg; ++sg) {
             // the segment record: 16 words, one scalar load
             const CWords sr = c_seg + 16 * sg;
@@ -430,7 +485,7 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                     } else {
                         // the matrix of the next position is read while the butterflies of the current one run
                         auto mload = [&](int p, v2d (&m)[4]) __attribute__((always_inline)) {
-                            const uint32_t ma = mat_a + 64u * (uint32_t)((ob >> (8 * p)) & 255);
+                            const uint32_t ma = mat_l + 64u * (uint32_t)((ob >> (8 * p)) & 255);
                             const bool need = ((oa >> p) & 1) && ((o_flags >> (2 * p)) & 3) != 3;      // wave-uniform
                             if (need) { m[0] = ldsr<v2d>(ma); m[1] = ldsr<v2d>(ma + 16u); m[2] = ldsr<v2d>(ma + 32u); m[3] = ldsr<v2d>(ma + 48u); }
                             else { m[0] = m[1] = m[2] = m[3] = (v2d){0.0, 0.0}; }
@@ -439,24 +494,30 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                             v2d ma[4], mb[4];
                             mload(0, ma);
                             mload(1, mb);
-                            if (oa & 1) u1_reg<0, NA>(v, ma[0], ma[1], ma[2], ma[3], o_flags & 3, scale);
+                            if (oa & 1) u1_reg<0, NA, PACK>(v, ma[0], ma[1], ma[2], ma[3], o_flags & 3, scale);
                             mload(2, ma);
-                            if (oa & 2) u1_reg<1, NA>(v, mb[0], mb[1], mb[2], mb[3], (o_flags >> 2) & 3, scale);
+                            if (oa & 2) u1_reg<1, NA, PACK>(v, mb[0], mb[1], mb[2], mb[3], (o_flags >> 2) & 3, scale);
                             mload(3, mb);
-                            if (oa & 4) u1_reg<2, NA>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 4) & 3, scale);
-                            if (oa & 8) u1_reg<3, NA>(v, mb[0], mb[1], mb[2], mb[3], (o_flags >> 6) & 3, scale);
+                            if (oa & 4) u1_reg<2, NA, PACK>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 4) & 3, scale);
+                            if (oa & 8) u1_reg<3, NA, PACK>(v, mb[0], mb[1], mb[2], mb[3], (o_flags >> 6) & 3, scale);
                         } else {      // 128 registers: one matrix at a time
                             v2d ma[4];
-                            if (oa & 1) { mload(0, ma); u1_reg<0, NA>(v, ma[0], ma[1], ma[2], ma[3], o_flags & 3, scale); }
-                            if (oa & 2) { mload(1, ma); u1_reg<1, NA>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 2) & 3, scale); }
-                            if (oa & 4) { mload(2, ma); u1_reg<2, NA>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 4) & 3, scale); }
+                            if (oa & 1) { mload(0, ma); u1_reg<0, NA, PACK>(v, ma[0], ma[1], ma[2], ma[3], o_flags & 3, scale); }
+                            if (oa & 2) { mload(1, ma); u1_reg<1, NA, PACK>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 2) & 3, scale); }
+                            if (oa & 4) { mload(2, ma); u1_reg<2, NA, PACK>(v, ma[0], ma[1], ma[2], ma[3], (o_flags >> 4) & 3, scale); }
                         }
                     }
                 } else if (kind == RG_DIAG || kind == RG_INIT) {
                     const int tb0 = o_tab;
-                    const uint32_t tlo = (uint32_t)tid & 15u, thi = (uint32_t)tid >> 4;
-                    const uint32_t ta = tab_a + 256u * (uint32_t)tb0;      // table A: the register bits
-                    v2d bt = cmul(ldsr<v2d>(ta + 256u + 16u * tlo), ldsr<v2d>(ta + 512u + 16u * thi));   // (thi >= 16: the second Bhi slot follows the first)
+                    const uint32_t ta = (kind == RG_INIT ? itab_l : dtab_l) + 256u * (uint32_t)tb0;      // table A: the register bits
+                    v2d bt;
+                    if constexpr (PACK) {      // the thread's bits above the circuit's qubits number the sample: not part of the table index
+                        bt = ldsr<v2d>(ta + 256u + 16u * ((uint32_t)tid & ((1u << n_lo) - 1u)));
+                        if (n_hi > 0) bt = cmul(bt, ldsr<v2d>(ta + 512u + 16u * (((uint32_t)tid >> 4) & ((1u << n_hi) - 1u))));
+                    } else {
+                        const uint32_t tlo = (uint32_t)tid & 15u, thi = (uint32_t)tid >> 4;
+                        bt = cmul(ldsr<v2d>(ta + 256u + 16u * tlo), ldsr<v2d>(ta + 512u + 16u * thi));   // (thi >= 16: the second Bhi slot follows the first)
+                    }
                     if (kind == RG_INIT) {
                         const int all_h = o_flags & 1;
                         if (all_h) {
@@ -472,10 +533,10 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                         const bool fresh = (o_flags & 256) != 0;      // the state is the identity times the running scale: write, do not multiply
                         bt = (v2d){bt.x * scale, bt.y * scale};
                         scale = 1.0;
-                        for (int k = 0; k < nTX; ++k) bt = cmul(bt, term_factor(term_at(rt_a, t0 + k), wt));
+                        for (int k = 0; k < nTX; ++k) bt = cmul(bt, term_factor(term_at(rt_l, t0 + k), wt));
                         v2d r0 = (v2d){1.0, 0.0}, r1 = r0, r2 = r0, r3 = r0;
                         for (int k = 0; k < nRT; ++k) {
-                            const TermL t = term_at(rt_a, t0 + nTX + k);
+                            const TermL t = term_at(rt_l, t0 + nTX + k);
                             const int rp = uni(t.rpos);
                             const uint32_t gb = rp == 0 ? 1u << g0 : (rp == 1 ? 1u << g1 : (rp == 2 ? 1u << g2 : 1u << g3));
                             const v2d f0 = term_factor(t, wt), f1 = term_factor(t, wt | gb);
@@ -537,10 +598,16 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
 #pragma unroll
                     for (int k = 0; k < NA; ++k) v[k] = (v2d){v[k].x * scale, v[k].y * scale};
                 }
-                // a wave-uniform base per register (scalar registers) plus ONE 32-bit lane offset
+                // a wave-uniform base per register (scalar registers) plus ONE 32-bit lane offset.  (PACK: `sample` is the
+                // group, a.D its 2^L amplitudes; a sample past the end of the batch is a copy of sample N - 1 and goes there.)
+                uint32_t wo = wt;
+                if constexpr (PACK) {
+                    const int64_t last = a.N - 1 - (sample << sbits);      // >= 0
+                    if ((int64_t)sid > last) wo = (wt & ((1u << nq) - 1u)) | ((uint32_t)last << nq);
+                }
                 if (a.psi32) {
                     char* gp = (char*)(a.psi32 + sample * a.D);
-                    uint32_t off = wt << 3;
+                    uint32_t off = wo << 3;
 #pragma unroll
                     for (int k = 0; k < NA; ++k) {
                         asm volatile("" : "+v"(off));      // keeps zext(off) at the store: selects the SGPR-base form
@@ -548,7 +615,7 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                     }
                 } else {
                     char* gp = (char*)(a.psi + sample * a.D);
-                    uint32_t off = wt << 4;
+                    uint32_t off = wo << 4;
 #pragma unroll
                     for (int k = 0; k < NA; ++k) {
                         asm volatile("" : "+v"(off));
@@ -561,33 +628,96 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
     }
 #ifdef QK_REG_TRACE
     if (tid0 == 0 && a.trace)
-        for (int k = 0; k < 8; ++k) a.trace[(int64_t)blockIdx.x * 8 + k] = k < 7 ? tr[k] : (double)(s_end - s_begin);
+        for (int k = 0; k < 12; ++k) a.trace[(int64_t)blockIdx.x * 12 + k] = k != 7 ? tr[k] : (double)(s_end - s_begin);
 #endif
 }
 
-int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* psi, void* psi32, hipStream_t stream) {
-    const int L = c.n_qubits;
+// The phase tables of the diagonal stages, for every sample of the batch: one thread per (sample, table), the samples of a
+// wave consecutive.  Which entries of a table take a term's factor (or its conjugate) is the same for every sample --
+// two 16-bit masks per (table, term) from the planner -- so the threads of a wave run one instruction stream of
+// coalesced angle loads and complex multiplications, without a select: inside the simulator the same products were one
+// lane per ENTRY of ONE sample, each a chain of LDS reads and selects (a fifth of a 12-qubit sample's time, most of an
+// 8-qubit one's).  The batch is padded to whole groups of 2^(L - nq) samples with copies of the last sample.
+__global__ void __launch_bounds__(256) reg_table_kernel(const char* blob, const double2* cs, int64_t N, int64_t n_pad, double2* out) {
+    const CWords hw = cwords(blob);
+    const int n_itab = hw[24], n_dtab = hw[3] - hw[24];
+    const int table = blockIdx.y;
+    const int64_t sample = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sample >= n_pad) return;
+    const int64_t src = sample < N ? sample : N - 1;
+    const CWords rec = cwords(blob + hw[12] + 32 * (n_itab + table));
+    const int t0 = rec[6], nt = rec[7];
+    const CWords tt = cwords(blob + hw[26]) + 2 * t0;
+    v2d f[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) f[x] = (v2d){1.0, 0.0};
+    for (int k = 0; k < nt; ++k) {
+        const int expr = tt[2 * k];
+        const uint32_t masks = (uint32_t)tt[2 * k + 1];
+        v2d u = (v2d){-1.0, 0.0};      // cz
+        if (expr >= 0) {
+            const double2 g = cs[(int64_t)expr * N + src];
+            u = (v2d){g.x, g.y};
+        }
+        const v2d uc = (v2d){u.x, -u.y};
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+            if ((masks >> x) & 1u) f[x] = cmul(f[x], ((masks >> (16 + x)) & 1u) ? uc : u);      // wave-uniform tests
+    }
+    v2d* o = (v2d*)out + ((sample * n_dtab + table) << 4);
+#pragma unroll
+    for (int x = 0; x < 16; ++x) o[x] = f[x];
+}
+
+// bytes of the stage tables of a batch of N samples (0: the circuit has no diagonal stage)
+size_t reg_table_bytes(const qk_circuit& c, int64_t N) {
     const RegHeader* H = (const RegHeader*)c.reg_blob.data();
-    const int RB = H->rb;
-    const void* fns[2][4] = {{(const void*)reg_sim_kernel<7, 3>, (const void*)reg_sim_kernel<8, 3>, (const void*)reg_sim_kernel<9, 3>, (const void*)reg_sim_kernel<10, 3>},
-                             {(const void*)reg_sim_kernel<6, 4>, (const void*)reg_sim_kernel<7, 4>, (const void*)reg_sim_kernel<8, 4>, (const void*)reg_sim_kernel<9, 4>}};
+    const int sb = H->L - H->nq;
+    const int64_t n_pad = ((N + ((int64_t)1 << sb) - 1) >> sb) << sb;
+    return (size_t)n_pad * (size_t)(H->n_tab - H->n_itab) * 256;
+}
+
+int launch_reg_tables(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* tabs, hipStream_t stream) {
+    const RegHeader* H = (const RegHeader*)c.reg_blob.data();
+    const int n_dtab = H->n_tab - H->n_itab, sb = H->L - H->nq;
+    if (n_dtab <= 0 || N <= 0) return QK_OK;
+    const int64_t n_pad = ((N + ((int64_t)1 << sb) - 1) >> sb) << sb;
+    if ((n_pad + 255) / 256 > 0x7fffffff) return fail(QK_ERR_UNSUPPORTED, "register-resident simulator: batch too large");
+    hipLaunchKernelGGL(reg_table_kernel, dim3((unsigned)((n_pad + 255) / 256), (unsigned)n_dtab), dim3(256), 0, stream,
+                       (const char*)blob_dev, cs, N, n_pad, (double2*)tabs);
+    QK_HIP(hipGetLastError());
+    return QK_OK;
+}
+
+int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs, const void* tabs, int64_t N, void* psi, void* psi32,
+                   hipStream_t stream) {
+    const RegHeader* H = (const RegHeader*)c.reg_blob.data();
+    const int L = H->L, RB = H->rb;      // L > n_qubits: 2^(L - n_qubits) samples per workgroup
+    const bool pack = H->nq < L;
+    const void* fns[3][4] = {{(const void*)reg_sim_kernel<7, 3, false>, (const void*)reg_sim_kernel<8, 3, false>, (const void*)reg_sim_kernel<9, 3, false>, (const void*)reg_sim_kernel<10, 3, false>},
+                             {(const void*)reg_sim_kernel<6, 4, false>, (const void*)reg_sim_kernel<7, 4, false>, (const void*)reg_sim_kernel<8, 4, false>, (const void*)reg_sim_kernel<9, 4, false>},
+                             {(const void*)reg_sim_kernel<6, 4, true>, (const void*)reg_sim_kernel<7, 4, true>, (const void*)reg_sim_kernel<8, 4, true>, nullptr}};
+    if (H->nq != c.n_qubits || L < kRegMinQubits || L > kRegMaxQubits || (pack && (RB != 4 || L > kRegPackMaxWidth)))
+        return fail(QK_ERR_INVALID, "register-resident simulator: malformed plan");
     static DeviceOnce attr_set;
     if (attr_set.pending()) {
-        for (int r = 0; r < 2; ++r)
-            for (int k = 0; k < 4; ++k) QK_HIP(hipFuncSetAttribute(fns[r][k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 4; ++k)
+                if (fns[r][k]) QK_HIP(hipFuncSetAttribute(fns[r][k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
     RegArgs a{};
     a.blob = (const char*)blob_dev;
     a.cs = cs;
+    a.tabs = (const double2*)tabs;
     a.N = N;
     a.psi = (double2*)psi;
     a.psi32 = (float2*)psi32;
     a.D = (int64_t)1 << L;
 #ifdef QK_REG_TRACE
     static double* trace_buf = nullptr;
-    if (!trace_buf) QK_HIP(hipMalloc((void**)&trace_buf, 8 * sizeof(double) * 256 * 16));
-    QK_HIP(hipMemsetAsync(trace_buf, 0, 8 * sizeof(double) * 256 * 16, stream));
+    if (!trace_buf) QK_HIP(hipMalloc((void**)&trace_buf, 12 * sizeof(double) * 256 * 16));
+    QK_HIP(hipMemsetAsync(trace_buf, 0, 12 * sizeof(double) * 256 * 16, stream));
     a.trace = trace_buf;
 #endif
     const size_t lds = c.reg_lds_bytes;
@@ -595,22 +725,25 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
     // resident workgroups per CU: LDS, and registers (RB = 4: 256 VGPRs, 8 waves per CU; RB = 3: 128 VGPRs, 16 waves)
     int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)std::max(1, (RB == 3 ? 1024 : 512) / threads));
     per_cu = std::max(1, per_cu);
-    const int64_t nblocks = std::min<int64_t>(N, (int64_t)256 * per_cu);
+    const int64_t n_group = (N + ((int64_t)1 << (L - H->nq)) - 1) >> (L - H->nq);
+    const int64_t nblocks = std::min<int64_t>(n_group, (int64_t)256 * per_cu);
     const dim3 grid((unsigned)nblocks), block(threads);
     void* args[] = {&a};
-    QK_HIP(hipLaunchKernel(fns[RB == 3 ? 0 : 1][L - 10], grid, block, args, lds, stream));
+    QK_HIP(hipLaunchKernel(fns[pack ? 2 : (RB == 3 ? 0 : 1)][L - 10], grid, block, args, lds, stream));
     QK_HIP(hipGetLastError());
 #ifdef QK_REG_TRACE
     {
         QK_HIP(hipStreamSynchronize(stream));
-        std::vector<double> h(8 * (size_t)nblocks);
+        std::vector<double> h(12 * (size_t)nblocks);
         QK_HIP(hipMemcpy(h.data(), trace_buf, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int64_t b = 0; b < nblocks; ++b)
-            for (int k = 0; k < 8; ++k) sum[k] += h[8 * b + k];
-        std::fprintf(stderr, "[reg trace] L=%d RB=%d blocks=%lld samples=%.0f us per sample and workgroup:", L, RB, (long long)nblocks, sum[7]);
-        const char* names[7] = {"before segments", "segment setup", "transpose read", "init/diag ops", "u1 ops", "other ops", "transpose write / stores"};
-        for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %s %.2f", names[k], sum[k] / sum[7] * 0.01);
+            for (int k = 0; k < 12; ++k) sum[k] += h[12 * b + k];
+        std::fprintf(stderr, "[reg trace] L=%d nq=%d RB=%d blocks=%lld groups=%.0f us per sample group and workgroup:", L, H->nq, RB, (long long)nblocks, sum[7]);
+        const char* names[12] = {"wait for angles", "segment setup", "transpose read", "init/diag ops", "u1 ops", "other ops", "transpose write / stores", "",
+                                 "barrier", "scatter", "composites", "tables"};
+        for (int k = 0; k < 12; ++k)
+            if (k != 7) std::fprintf(stderr, " %s %.2f", names[k], sum[k] / sum[7] * 0.01);
         std::fprintf(stderr, "\n");
     }
 #endif

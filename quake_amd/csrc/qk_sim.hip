@@ -1281,19 +1281,42 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         const char* e = std::getenv("QK_SIM_PATH");
         return !e ? 0 : (std::strcmp(e, "reg") == 0 ? 1 : (std::strcmp(e, "noreg") == 0 || std::strcmp(e, "lds") == 0 || std::strcmp(e, "wave") == 0 ? -1 : 0));
     }();
-    if (dt.reg && !rdm_dev && reg_mode >= 0 && (reg_mode > 0 || (!direct_shape && n >= 11))) {
+    // Below 10 qubits the plan packs several samples into a workgroup; it takes over from the wave-resident kernel
+    // once the batch is large enough to fill the chip with such groups (small batches: one launch less there).
+    const bool reg_pays = n >= 11 || (n < kRegMinQubits && (N << n) >= ((int64_t)1 << 21));
+    if (dt.reg && !rdm_dev && reg_mode >= 0 && (reg_mode > 0 || (!direct_shape && reg_pays))) {
         const RegHeader* H = (const RegHeader*)c.reg_blob.data();
-        double2* cs = nullptr;
-        if (H->n_expr > 0) {
-            if ((N + 63) / 64 > 0x7fffffff) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
-            QK_HIP(hipMallocAsync((void**)&cs, (size_t)H->n_expr * (size_t)N * sizeof(double2), (hipStream_t)stream));
-            hipLaunchKernelGGL(angle_table_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((H->n_expr + 3) / 4)), dim3(256), 0,
-                               (hipStream_t)stream, (const DevExpr*)((const char*)dt.reg + H->off_expr), H->n_expr, dt.prog, dt.consts,
-                               X_dev, ldx, N, cs);
+        // The angles and the stage tables of the batch live in stream order.  Large batches go in chunks of whole sample
+        // groups so that those two tables stay within 256 MiB whatever N is.
+        const int64_t per_sample = (int64_t)H->n_expr * 16 + (int64_t)(H->n_tab - H->n_itab) * 256;
+        const int64_t group = (int64_t)1 << (H->L - H->nq);
+        int64_t chunk = per_sample > 0 ? std::max<int64_t>(((int64_t)256 << 20) / per_sample, 65536) : N;
+        chunk = std::min<int64_t>(N, chunk / group * group);
+        for (int64_t s0 = 0; s0 < N; s0 += chunk) {
+            const int64_t Nc = std::min(chunk, N - s0);
+            double2* cs = nullptr;
+            void* tabs = nullptr;
+            if (H->n_expr > 0) {
+                if ((Nc + 63) / 64 > 0x7fffffff) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
+                QK_HIP(hipMallocAsync((void**)&cs, (size_t)H->n_expr * (size_t)Nc * sizeof(double2), (hipStream_t)stream));
+                hipLaunchKernelGGL(angle_table_kernel, dim3((unsigned)((Nc + 63) / 64), (unsigned)((H->n_expr + 3) / 4)), dim3(256), 0,
+                                   (hipStream_t)stream, (const DevExpr*)((const char*)dt.reg + H->off_expr), H->n_expr, dt.prog, dt.consts,
+                                   X_dev + s0 * ldx, ldx, Nc, cs);
+            }
+            const size_t tb = reg_table_bytes(c, Nc);
+            rc = QK_OK;
+            if (tb > 0) {
+                if (hipMallocAsync(&tabs, tb, (hipStream_t)stream) != hipSuccess) rc = fail(QK_ERR_HIP, "qk_simulate_dev: cannot allocate the phase tables");
+                if (rc == QK_OK) rc = launch_reg_tables(c, dt.reg, cs, Nc, tabs, (hipStream_t)stream);
+            }
+            if (rc == QK_OK)
+                rc = launch_reg_sim(c, dt.reg, cs, tabs, Nc, psi32_dev ? nullptr : (void*)((double2*)psi_dev + (s0 << n)),
+                                    psi32_dev ? (void*)((float2*)psi32_dev + (s0 << n)) : nullptr, (hipStream_t)stream);
+            if (cs) (void)hipFreeAsync(cs, (hipStream_t)stream);
+            if (tabs) (void)hipFreeAsync(tabs, (hipStream_t)stream);
+            if (rc != QK_OK) return rc;
         }
-        rc = launch_reg_sim(c, dt.reg, cs, N, psi32_dev ? nullptr : psi_dev, psi32_dev, (hipStream_t)stream);
-        if (cs) (void)hipFreeAsync(cs, (hipStream_t)stream);
-        return rc;
+        return QK_OK;
     }
     if (dt.wave && !rdm_dev && !force_lds && !prefer_lds) {
         WaveJob job{};

@@ -260,6 +260,32 @@ def test_register_resident_simulator_many_samples(n, seed, N):
     del psi, psi32
 
 
+@pytest.mark.parametrize("n,seed,N,gates", [(4, 30, 131072 + 37, 8), (5, 31, 65536 + 5, 16), (6, 32, 40000 + 1, 54), (7, 33, 20000 + 3, 63),
+                                            (8, 34, 9000 + 7, 72), (9, 35, 4096 + 1, 81)])
+def test_register_resident_simulator_packed_samples(n, seed, N, gates):
+    """4 to 9 qubits: several samples share a workgroup of the register-resident kernel (index bits above the circuit's
+    qubits number the sample).  Gate soups as above; N is not a multiple of the group size, so the last group is
+    short; every row is compared with the oracle's simulator (narrow states: cheap), in FP64 and in FP32-output mode."""
+    import torch
+    from quake_amd import device as qdev
+    c = _gate_soup(n, seed, gates)
+    h = HipFidelityKernel(c)._circuit()
+    assert h.num_passes == 1 and "register-resident plan" in h.plan_summary and " 1 samples per workgroup" not in h.plan_summary
+    X = synth_X(N, 5, "scaled", 900 + n)
+    dc = qdev.DeviceCircuit(c)
+    Xd = torch.from_numpy(X).cuda()
+    guard = torch.full((N + 64, 1 << n), 7.0, dtype=torch.complex128, device="cuda")      # rows past N must stay untouched
+    psi = dc.simulate(Xd, out=guard[:N])
+    ref = psi_from_compiled(c, X)
+    assert np.abs(psi.cpu().numpy() - ref).max() < TOL_PSI
+    assert bool((guard[N:] == 7.0).all())
+    psi32 = dc.simulate(Xd, dtype=torch.complex64)
+    assert np.abs(psi32.cpu().numpy() - ref).max() < 2e-7
+    # a batch smaller than one group, and one sample
+    for small in (1, 3):
+        assert np.abs(dc.simulate(Xd[:small].contiguous()).cpu().numpy() - ref[:small]).max() < TOL_PSI
+
+
 @pytest.mark.parametrize("n,seed", [(1, 0), (3, 1), (7, 2), (10, 3), (11, 4), (12, 5), (14, 6)])
 def test_statevectors_single_qubit_runs(n, seed):
     """Long runs of single-qubit gates on one qubit between rare two-qubit gates (the shape of a GA genome
