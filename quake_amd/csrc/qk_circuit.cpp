@@ -661,42 +661,36 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         std::vector<RegTerm> rterms;      // terms the simulator evaluates per thread (between two thread bits, or a register and a thread bit)
         struct TabTerm { int type, va, vb, tag; };
         std::vector<TabTerm> tterms;      // terms that live in a phase table (reg_table_kernel)
-        constexpr int kNoDst = 0x7fffffff;   // DevExpr::dst of an angle only the table kernel reads (DevExpr::gate = its tterm)
+        // DevExpr::dst of an angle that only a pre-pass kernel reads: a table term (DevExpr::gate = its tterm) or a factor of
+        // a matrix (DevExpr::gate = its RegFact); every other dst is a term of `rterms`
+        constexpr int kTabDst = 0x7fffffff, kMatDst = 0x7ffffffe;
         int n_itab = 0;
         std::vector<DevExpr> rexprs;
-        std::vector<DevMat> rmats;
-        std::vector<DevComp> rcomps;
-        std::vector<int32_t> rfacts;
+        std::vector<RegMat> rmats;        // the matrices the simulator reads, as products of factors (reg_matrix_kernel)
+        std::vector<RegFact> rfacts;
         std::vector<int32_t> init_mat(n, -1);
         auto r_expr = [&](int e, double scale, int dst, int gate = 0) {
             rexprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale, dst, gate});
         };
+        auto r_factor = [&](int gate, int expr) {
+            rfacts.push_back(RegFact{gate, -1});
+            if (expr >= 0) r_expr(expr, gate == QK_P ? 1.0 : 0.5, kMatDst, (int)rfacts.size() - 1);
+        };
         auto r_matrix = [&](const Item& g) {
+            RegMat m{(int)rfacts.size(), 1};
             if (g.gate != QK_UC) {
-                rmats.push_back(DevMat{g.gate, 0});
-                const int mi = (int)rmats.size() - 1;
-                if (g.expr >= 0) r_expr(g.expr, 0.5, ~mi, g.gate);
-                return mi;
+                r_factor(g.gate, g.expr);
+            } else {
+                m.count = (int)comps[g.expr].size();
+                for (const Factor& f : comps[g.expr]) r_factor(f.gate, f.expr);
             }
-            DevComp dc{};
-            dc.first = (int)rfacts.size();
-            dc.count = (int)comps[g.expr].size();
-            for (const Factor& f : comps[g.expr]) {
-                rmats.push_back(DevMat{f.gate, 0});
-                const int fi = (int)rmats.size() - 1;
-                if (f.expr >= 0) r_expr(f.expr, f.gate == QK_P ? 1.0 : 0.5, ~fi, f.gate);
-                rfacts.push_back(fi);
-            }
-            rmats.push_back(DevMat{QK_UC, 0});
-            dc.dst = (int)rmats.size() - 1;
-            rcomps.push_back(dc);
-            return dc.dst;
+            rmats.push_back(m);
+            return (int)rmats.size() - 1;
         };
         bool all_h = (int)inits.size() == n;
-        for (const Item& g : inits) {
-            init_mat[g.q0] = r_matrix(g);
-            all_h = all_h && g.gate == QK_H;
-        }
+        for (const Item& g : inits) all_h = all_h && g.gate == QK_H;
+        if (!all_h)      // (an all-Hadamard first layer is the constant 2^(-n/2): no matrices)
+            for (const Item& g : inits) init_mat[g.q0] = r_matrix(g);
         auto table = [&](const std::vector<int>& bits, size_t from, uint32_t fixed, int t0, int nt) {
             RegTab t{};
             t.nbits = (int)std::min<size_t>(4, bits.size() - std::min(from, bits.size()));
@@ -780,7 +774,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                             tterms.push_back(TabTerm{t.kind, t.q0, t.q1 >= 0 ? t.q1 : 0, -1});
                             if (t.expr >= 0) {
                                 tterms.back().tag = (int)tterms.size() - 1;
-                                r_expr(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, kNoDst, (int)tterms.size() - 1);
+                                r_expr(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, kTabDst, (int)tterms.size() - 1);
                             }
                         }
                     }
@@ -793,10 +787,11 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                             rt.type = t.kind;
                             rt.va = t.q0;
                             rt.vb = t.q1 >= 0 ? t.q1 : 0;
-                            rt.rpos = 0;
+                            rt.expr = -1;
                             if (k == 4) {
-                                rt.rpos = in(g.bits, t.q0) ? rpos(t.q0) : rpos(t.q1);
-                                op.flags |= 1 << rt.rpos;
+                                const int rp = in(g.bits, t.q0) ? rpos(t.q0) : rpos(t.q1);
+                                rt.type |= rp << 8;
+                                op.flags |= 1 << rp;
                             }
                             rterms.push_back(rt);
                             if (t.expr >= 0) r_expr(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, (int)rterms.size() - 1);
@@ -814,7 +809,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 } else if (p.nd.kind == ST_U1) {
                     // gates on distinct register qubits commute: up to four of them travel as ONE op (one record, the
                     // matrices read together) -- a layer of Hadamards on the group is a single op without matrices
-                    const int pos = rpos(p.nd.q0), mi = r_matrix(p.nd);
+                    const int pos = rpos(p.nd.q0), mi = p.nd.gate == QK_H ? 0 : r_matrix(p.nd);      // (a Hadamard is adds and subtractions)
                     const int gate = p.nd.gate;      // butterfly form: 3 hadamard (adds only), 0 real matrix, 1 rx-shaped, 2 general
                     const int form = gate == QK_H ? 3 : ((gate == QK_X || gate == QK_RY) ? 0 : (gate == QK_RX ? 1 : 2));
                     if (!rops.empty() && (int)rops.size() > sg.op0 && rops.back().kind == RG_U1 && !((rops.back().a >> pos) & 1)) {
@@ -849,16 +844,20 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             for (int k = 0; k < e.len; ++k) hsh = (hsh ^ (uint64_t)(c.prog[e.start + k].op + 1)) * 1099511628211ull;
             return hsh ^ (uint64_t)e.len;
         };
+        auto pre_only = [&](const DevExpr& e) { return e.dst == kTabDst || e.dst == kMatDst; };
         std::stable_sort(rexprs.begin(), rexprs.end(), [&](const DevExpr& x, const DevExpr& y) {
-            if ((x.dst == kNoDst) != (y.dst == kNoDst)) return y.dst == kNoDst;
+            if (pre_only(x) != pre_only(y)) return pre_only(y);
             if (x.len != y.len) return x.len > y.len;
             return shape(x) < shape(y);
         });
         size_t n_expr_k = 0;
-        for (size_t e = 0; e < rexprs.size(); ++e) {
-            if (rexprs[e].dst == kNoDst) tterms[rexprs[e].gate].tag = (int)e;      // where the term finds its (cos, sin)
-            else n_expr_k = e + 1;
+        std::vector<int32_t> term_expr(rterms.size(), -1);
+        for (size_t e = 0; e < rexprs.size(); ++e) {      // where the terms and factors find their (cos, sin)
+            if (rexprs[e].dst == kTabDst) tterms[rexprs[e].gate].tag = (int)e;
+            else if (rexprs[e].dst == kMatDst) rfacts[rexprs[e].gate].expr = (int)e;
+            else { term_expr[rexprs[e].dst] = (int)e; n_expr_k = e + 1; }
         }
+        for (size_t t = 0; t < rterms.size(); ++t) rterms[t].expr = term_expr[t];
         // the table kernel's records: which entries of a table take a term's factor, which its conjugate
         std::vector<RegTabTerm> tts;
         for (size_t ti = (size_t)n_itab; ti < tabs.size(); ++ti) {
@@ -880,19 +879,20 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             tb.t0 = first;
         }
         const bool fits = (int)tabs.size() <= kRegMaxTabs && (int)rterms.size() <= kRegMaxTerms && (int)rmats.size() <= std::min(kRegMaxMats, 255);
-        // LDS: the transpose image; per sample: terms, matrices, product-state tables (unless all-Hadamard) and two buffers
-        // of stage tables; the staged records; two angle buffers
+        // LDS: the transpose image; the terms evaluated per thread; per sample the product-state tables (unless all-Hadamard);
+        // two buffers each of a group's stage tables + matrices (from the pre-pass kernels) and of its angles; staged records
         const size_t n_dtab = tabs.size() - (size_t)n_itab, n_itab_built = all_h ? 0 : (size_t)n_itab;
         const size_t n_slot = ((size_t)n_samp * n_expr_k + 63) / 64 * 64;      // slots of 64 (cos, sin) pairs
-        const size_t t_slot = ((size_t)n_samp * n_dtab * 16 + 63) / 64;        // slots of 64 table entries
-        // (the stage tables of the NEXT group arrive while this one computes: two buffers -- one, filled at the top of a
-        // group's turn, when two do not fit even a lone workgroup per CU: deep circuits at 13 qubits)
-        const size_t lds_but_tabs = ((size_t)16 << Lv) + (size_t)n_samp * (32 * rterms.size() + 64 * rmats.size() + 256 * n_itab_built) +
-                           32 * (size_t)n_itab + 16 * rcomps.size() + 8 * n_expr_k + 4 * rfacts.size() + 4 * (size_t)n + 64 + 32 * n_slot;
-        const bool tab_single = lds_but_tabs + 2048 * t_slot > lds_limit && lds_limit >= (size_t)160 * 1024;
-        const size_t lds = lds_but_tabs + (tab_single ? 1024 : 2048) * t_slot;
+        const size_t side_piece = (size_t)n_samp * (n_dtab * 16 + rmats.size() * 4);      // 16-byte pieces of a group's tables and matrices
+        const size_t t_slot = (side_piece + 63) / 64;
+        // (the tables and matrices of the NEXT group arrive while this one computes: two buffers -- one, filled at the top
+        // of a group's turn, when two do not fit even a lone workgroup per CU: deep circuits at 13 qubits)
+        const size_t lds_but_side = ((size_t)16 << Lv) + 16 * rterms.size() + (size_t)n_samp * 256 * n_itab_built + 32 * (size_t)n_itab +
+                                    4 * (size_t)n + 64 + 32 * n_slot;
+        const bool tab_single = lds_but_side + 2048 * t_slot > lds_limit && lds_limit >= (size_t)160 * 1024;
+        const size_t lds = lds_but_side + (tab_single ? 1024 : 2048) * t_slot;
         const size_t waves = std::max<size_t>(1, ((size_t)1 << (Lv - RB)) / 64);
-        const size_t nd = (n_slot / 64 + waves - 1) / waves + (t_slot + waves - 1) / waves;    // fetches per wave and sample group (up to 8: counted waits)
+        const size_t nd = (n_slot / 64 + waves - 1) / waves + (t_slot + waves - 1) / waves;    // fetch instructions per wave and sample group
         if (std::getenv("QK_REG_DEBUG")) std::fprintf(stderr, "[reg plan] Lv=%d fits=%d nd=%zu lds=%zu limit=%zu tabs=%zu terms=%zu mats=%zu\n", Lv, (int)fits, nd, lds, lds_limit, tabs.size(), rterms.size(), rmats.size());
         if (!(fits && nd <= 64 && lds <= lds_limit)) return false;
         {
@@ -901,7 +901,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             H.L = Lv;
             H.nq = n;
             H.n_seg = (int)segs.size(); H.n_op = (int)rops.size(); H.n_tab = (int)tabs.size(); H.n_term = (int)rterms.size();
-            H.n_expr = (int)rexprs.size(); H.n_mat = (int)rmats.size(); H.n_comp = (int)rcomps.size(); H.n_fact = (int)rfacts.size();
+            H.n_expr = (int)rexprs.size(); H.n_mat = (int)rmats.size(); H.n_comp = 0; H.n_fact = (int)rfacts.size();
             H.init_h = (all_h ? 1 : 0) | (tab_single ? 2 : 0);
             H.rb = RB;
             H.init_c = std::ldexp((n & 1) ? 0.70710678118654752440 : 1.0, -(n / 2));
@@ -912,9 +912,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             H.off_tab = (int)off;  off = pad16(off + tabs.size() * sizeof(RegTab));
             H.off_term = (int)off; off = pad16(off + rterms.size() * sizeof(RegTerm));
             H.off_expr = (int)off; off = pad16(off + rexprs.size() * sizeof(DevExpr));
-            H.off_mat = (int)off;  off = pad16(off + rmats.size() * sizeof(DevMat));
-            H.off_comp = (int)off; off = pad16(off + rcomps.size() * sizeof(DevComp));
-            H.off_fact = (int)off; off = pad16(off + rfacts.size() * sizeof(int32_t));
+            H.off_mat = (int)off;  off = pad16(off + rmats.size() * sizeof(RegMat));
+            H.off_comp = (int)off;
+            H.off_fact = (int)off; off = pad16(off + rfacts.size() * sizeof(RegFact));
             H.off_init = (int)off; off = pad16(off + init_mat.size() * sizeof(int32_t));
             H.off_tt = (int)off;   off = pad16(off + tts.size() * sizeof(RegTabTerm));
             H.bytes = (int)off;
@@ -927,9 +927,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             put(H.off_tab, tabs.data(), tabs.size() * sizeof(RegTab));
             put(H.off_term, rterms.data(), rterms.size() * sizeof(RegTerm));
             put(H.off_expr, rexprs.data(), rexprs.size() * sizeof(DevExpr));
-            put(H.off_mat, rmats.data(), rmats.size() * sizeof(DevMat));
-            put(H.off_comp, rcomps.data(), rcomps.size() * sizeof(DevComp));
-            put(H.off_fact, rfacts.data(), rfacts.size() * sizeof(int32_t));
+            put(H.off_mat, rmats.data(), rmats.size() * sizeof(RegMat));
+            put(H.off_fact, rfacts.data(), rfacts.size() * sizeof(RegFact));
             put(H.off_init, init_mat.data(), init_mat.size() * sizeof(int32_t));
             put(H.off_tt, tts.data(), tts.size() * sizeof(RegTabTerm));
             c.reg_lds_bytes = lds;

@@ -18,7 +18,7 @@ constexpr int kRegPackMaxWidth = 12;  // ... of at most 12 (256 threads)
 constexpr int kRegMaxQubits = 13;     // 512 threads x 16 amplitudes = 128 KiB of LDS for the transposes
 constexpr int kRegMaxTabs = 96;       // phase tables of 16 entries (256 bytes each) per sample
 constexpr int kRegMaxTerms = 256;
-constexpr int kRegMaxMats = 160;
+constexpr int kRegMaxMats = 255;      // (a byte per register position in RegOp::b)
 
 enum RegOpKind : int32_t {
     RG_INIT = 0,   // the product state of the hoisted first gates (tab: three or four tables of first-column products)
@@ -65,10 +65,18 @@ struct RegTabTerm {   // 8 bytes: one diagonal term's part in one table
     uint32_t masks;   // bit x: entry x takes the factor; bit 16 + x: ... its conjugate (rz with the bit clear)
 };
 
-struct RegTerm {      // static part of a diagonal term
-    int32_t type;     // TermKind
+struct RegTerm {      // 16 bytes: a diagonal term the simulator evaluates per thread (staged in LDS as it is)
+    int32_t type;     // TermKind | rpos << 8 (RT terms: register position of the term's register bit)
     int32_t va, vb;
-    int32_t rpos;     // RT terms: register position of the term's register bit
+    int32_t expr;     // its (cos, sin) among the first n_expr_k angle programs; < 0: the constant -1 (cz)
+};
+
+struct RegMat {       // a 2x2 matrix the simulator reads: the product of the factors [first, first + count), first one applied first
+    int32_t first, count;
+};
+struct RegFact {
+    int32_t gate;     // QK_H, QK_X, QK_SX, QK_RX, QK_RY, QK_RZ, QK_P
+    int32_t expr;     // angle program of a parametric gate, -1 otherwise
 };
 
 struct RegHeader {    // at offset 0 of the blob; off_* are byte offsets from its start (16-byte aligned sections)

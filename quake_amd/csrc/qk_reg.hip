@@ -36,7 +36,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));   // native vector: stay
 struct RegArgs {
     const char* blob;      // RegHeader + tables (device)
     const double2* cs;     // (cos, sin) of every angle program, [expr][sample]
-    const double2* tabs;   // phase tables of the diagonal stages, [sample, padded to whole groups][table][16] (reg_table_kernel)
+    const double2* side;   // per group of samples: the phase tables of its diagonal stages [sample][table][16], then its matrices
+                           // [sample][matrix][4] (reg_table_kernel, reg_matrix_kernel; the batch padded to whole groups)
     int64_t N;
     double2* psi;
     float2* psi32;         // FP32 output: the state is evolved in FP64 and rounded once, at the store
@@ -79,10 +80,12 @@ template <class T> __device__ __forceinline__ void ldsw(uint32_t addr, T v) { *(
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef int int2v __attribute__((ext_vector_type(2)));
 struct TermL { double c, s; int type, va, vb, rpos; };
-__device__ __forceinline__ TermL term_at(uint32_t rt_a, int t) {
-    const v2d cs = ldsr<v2d>(rt_a + 32u * (uint32_t)t);
-    const int4v k = ldsr<int4v>(rt_a + 32u * (uint32_t)t + 16u);
-    return TermL{cs.x, cs.y, k.x, k.y, k.z, k.w};
+// term t: its record (staged RegTerm) and the (cos, sin) of its angle for this lane's sample (cs_l: the lane's base in the
+// angle buffer, sb = log2 of the samples per group)
+__device__ __forceinline__ TermL term_at(uint32_t rts_a, uint32_t cs_l, int sb, int t) {
+    const int4v k = ldsr<int4v>(rts_a + 16u * (uint32_t)t);
+    const v2d cs = ldsr<v2d>(cs_l + ((uint32_t)(k.w < 0 ? 0 : k.w) << (4 + sb)));
+    return TermL{k.w < 0 ? -1.0 : cs.x, k.w < 0 ? 0.0 : cs.y, k.x & 255, k.y, k.z, k.x >> 8};
 }
 __device__ __forceinline__ v2d term_factor(const TermL& t, uint32_t w) {
     const uint32_t ba = (w >> t.va) & 1u, bb = (w >> t.vb) & 1u;
@@ -101,21 +104,6 @@ __device__ __forceinline__ void with_pos(int p, F&& f) {      // p is wave-unifo
     else if (p == 1) f(IC<1>());
     else if (p == 2) f(IC<2>());
     else f(IC<3>());
-}
-
-// (cos, sin) of one angle into the diagonal term or the 2x2 matrix it feeds (as the LDS kernel's scatter_angle)
-__device__ __forceinline__ void scatter_angle(int dst, int gate, double cn, double sn, uint32_t rt_a, uint32_t mat_a) {
-    if (dst >= 0) {
-        ldsw<v2d>(rt_a + 32u * (uint32_t)dst, (v2d){cn, sn});
-        return;
-    }
-    const uint32_t m = mat_a + 64u * (uint32_t)(~dst);
-    v2d m0, m1, m2, m3;
-    if (gate == QK_RX) { m0 = (v2d){cn, 0}; m1 = (v2d){0, -sn}; m2 = (v2d){0, -sn}; m3 = (v2d){cn, 0}; }
-    else if (gate == QK_RZ) { m0 = (v2d){cn, -sn}; m1 = (v2d){0, 0}; m2 = (v2d){0, 0}; m3 = (v2d){cn, sn}; }
-    else if (gate == QK_P) { m0 = (v2d){1, 0}; m1 = (v2d){0, 0}; m2 = (v2d){0, 0}; m3 = (v2d){cn, sn}; }
-    else { m0 = (v2d){cn, 0}; m1 = (v2d){-sn, 0}; m2 = (v2d){sn, 0}; m3 = (v2d){cn, 0}; }
-    ldsw<v2d>(m, m0); ldsw<v2d>(m + 16u, m1); ldsw<v2d>(m + 32u, m2); ldsw<v2d>(m + 48u, m3);
 }
 
 // a 2x2 matrix on register position P: eight butterflies between registers k and k | (1 << P).  form: 0 real matrix
@@ -222,32 +210,26 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
     const int nq = PACK ? hw[21] : L;                  // qubits of the circuit
     const int sbits = L - nq, S = 1 << sbits;           // samples per workgroup
     static_assert(offsetof(RegHeader, nq) == 84, "RegHeader is read word by word");
-    const int n_seg = hw[1], n_term = hw[4], n_mat = hw[6], n_comp = hw[7], n_fact = hw[8], init_h = hw[9];
+    const int n_seg = hw[1], n_term = hw[4], n_mat = hw[6], init_h = hw[9];
     const int n_itab = hw[24], n_dtab = hw[3] - hw[24], n_expr = hw[27];      // n_expr: the angle programs the simulator reads itself
-    const int off_seg = hw[10], off_op = hw[11], off_tab = hw[12], off_term = hw[13], off_expr = hw[14], off_mat = hw[15],
-              off_comp = hw[16], off_fact = hw[17], off_init = hw[18];
+    const int off_seg = hw[10], off_op = hw[11], off_tab = hw[12], off_term = hw[13], off_init = hw[18];
     const double init_c = ((const double*)(a.blob + 88))[0];
     static_assert(sizeof(RegHeader) == 112 && offsetof(RegHeader, init_c) == 88 && offsetof(RegHeader, n_itab) == 96 && offsetof(RegHeader, n_expr_k) == 108 &&
-                      sizeof(RegSeg) == 64, "RegHeader and RegSeg are read word by word");
-    // LDS map (32-bit LDS addresses: see ldsr / ldsw): the transpose image, then per-sample terms, matrices and tables,
-    // then what is staged once per workgroup, then two buffers of angles
-    const uint32_t state_a = (uint32_t)(size_t)(lptr_t)lds;
-    // (per sample: terms, matrices, tables of the product state; then two buffers of stage tables, the staged records, two
-    // buffers of angles)
+                      sizeof(RegSeg) == 64 && sizeof(RegTerm) == 16, "RegHeader, RegSeg and RegTerm are read word by word");
+    // LDS map (32-bit LDS addresses: see ldsr / ldsw): the transpose image; the terms evaluated per thread; per sample the
+    // tables of the product state; one or two buffers of a group's stage tables and matrices (reg_table_kernel,
+    // reg_matrix_kernel: fetched by LDS-DMA); the staged records; two buffers of angles (those of the per-thread terms)
     const int n_ib = (init_h & 1) ? 0 : n_itab;      // product-state tables are built here, unless every first gate is a Hadamard
-    const bool tab_single = (init_h & 2) != 0;      // one buffer of stage tables: fetched at the top of the group's own turn
-    const uint32_t rt_s = 32u * (uint32_t)n_term, mat_s = 64u * (uint32_t)n_mat, itab_s = 256u * (uint32_t)n_ib, dtab_s = 256u * (uint32_t)n_dtab;
-    const int t_piece = (S * n_dtab) << 4;                          // 16-byte entries of a group's stage tables
-    const uint32_t dt_bytes = (uint32_t)((t_piece + 63) & ~63) << 4;   // one buffer: whole fetch instructions of 64 entries
-    const uint32_t rt_a = state_a + (16u << L);                     // 32 B per term: (cos, sin), type, va, vb, rpos
-    const uint32_t mat_a = rt_a + rt_s * (uint32_t)S;               // 64 B per matrix
-    const uint32_t itab_a = mat_a + mat_s * (uint32_t)S;            // 256 B per table
-    const uint32_t dtab_a = itab_a + itab_s * (uint32_t)S;
-    const uint32_t stab_a = dtab_a + (tab_single ? 1u : 2u) * dt_bytes;                 // RegTab records of the product-state tables, 32 B
-    const uint32_t comp_a = stab_a + 32u * (uint32_t)n_itab;        // DevComp records, 16 B
-    const uint32_t sexpr_a = comp_a + 16u * (uint32_t)n_comp;       // (dst, gate) of every angle program, 8 B
-    const uint32_t fact_a = sexpr_a + 8u * (uint32_t)n_expr;
-    const uint32_t init_a = fact_a + 4u * (uint32_t)n_fact;
+    const bool side_single = (init_h & 2) != 0;      // one buffer of tables and matrices: fetched at the top of the group's own turn
+    const uint32_t itab_s = 256u * (uint32_t)n_ib, dtab_s = 256u * (uint32_t)n_dtab, mat_s = 64u * (uint32_t)n_mat;      // per sample
+    const int t_piece = (S * n_dtab) << 4, side_piece = t_piece + ((S * n_mat) << 2);      // 16-byte pieces of a group's tables (+ matrices)
+    const uint32_t side_bytes = (uint32_t)((side_piece + 63) & ~63) << 4;               // one buffer: whole fetch instructions of 64 pieces
+    const uint32_t state_a = (uint32_t)(size_t)(lptr_t)lds;
+    const uint32_t rts_a = state_a + (16u << L);                    // RegTerm records, 16 B
+    const uint32_t itab_a = rts_a + 16u * (uint32_t)n_term;         // 256 B per table
+    const uint32_t side_a = itab_a + itab_s * (uint32_t)S;
+    const uint32_t stab_a = side_a + (side_single ? 1u : 2u) * side_bytes;      // RegTab records of the product-state tables, 32 B
+    const uint32_t init_a = stab_a + 32u * (uint32_t)n_itab;
     const int n_slot = (n_expr * S + 63) & ~63;                     // one slot of 64 pairs per fetch instruction; pair e * S + s
     const uint32_t cs_a = (init_a + 4u * (uint32_t)nq + 15u) & ~15u;   // two buffers of n_slot (cos, sin) pairs
     const CWords c_seg = cwords(a.blob + off_seg), c_op = cwords(a.blob + off_op);
@@ -255,33 +237,9 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
     if (state_a & ((16u << L) - 1u)) __builtin_trap();      // the swizzled image must start where its address bits are clear (dynamic LDS starts at 0)
 
     // ---- once per workgroup: what does not depend on the sample -----------------------------------------------
-    for (int i = tid0; i < n_term * S; i += T) {      // (every sample of the group has its copy: i = t * S + s)
-        const int t = i >> sbits;
-        const RegTerm d = ((const RegTerm*)(a.blob + off_term))[t];
-        const uint32_t at = rt_a + rt_s * (uint32_t)(i & (S - 1)) + 32u * (uint32_t)t;
-        ldsw<v2d>(at, (v2d){-1.0, 0.0});     // TM_CZ; parametric terms get (cos, sin) per sample
-        ldsw<int4v>(at + 16u, (int4v){d.type, d.va, d.vb, d.rpos});
-    }
-    for (int i = tid0; i < n_mat * S; i += T) {
-        const int m_i = i >> sbits;
-        const int gate = ((const DevMat*)(a.blob + off_mat))[m_i].gate;
-        const double r = 0.70710678118654752440;
-        v2d m00 = (v2d){0, 0}, m01 = m00, m10 = m00, m11 = m00;
-        if (gate == QK_H) { m00 = (v2d){r, 0}; m01 = (v2d){r, 0}; m10 = (v2d){r, 0}; m11 = (v2d){-r, 0}; }
-        else if (gate == QK_X) { m01 = (v2d){1, 0}; m10 = (v2d){1, 0}; }
-        else if (gate == QK_SX) { m00 = (v2d){0.5, 0.5}; m01 = (v2d){0.5, -0.5}; m10 = (v2d){0.5, -0.5}; m11 = (v2d){0.5, 0.5}; }
-        const uint32_t at = mat_a + mat_s * (uint32_t)(i & (S - 1)) + 64u * (uint32_t)m_i;
-        ldsw<v2d>(at, m00); ldsw<v2d>(at + 16u, m01);
-        ldsw<v2d>(at + 32u, m10); ldsw<v2d>(at + 48u, m11);
-    }
+    for (int t = tid0; t < 4 * n_term; t += T) ldsw<int>(rts_a + 4u * t, ((const int32_t*)(a.blob + off_term))[t]);
     for (int t = tid0; t < 8 * n_itab; t += T) ldsw<int>(stab_a + 4u * t, ((const int32_t*)(a.blob + off_tab))[t]);
     for (int q = tid0; q < nq; q += T) ldsw<int>(init_a + 4u * q, ((const int32_t*)(a.blob + off_init))[q]);
-    for (int e = tid0; e < n_expr; e += T) {
-        const DevExpr ex = ((const DevExpr*)(a.blob + off_expr))[e];
-        ldsw<int2v>(sexpr_a + 8u * e, (int2v){ex.dst, ex.gate});
-    }
-    for (int k = tid0; k < 4 * n_comp; k += T) ldsw<int>(comp_a + 4u * k, ((const int32_t*)(a.blob + off_comp))[k]);
-    for (int k = tid0; k < n_fact; k += T) ldsw<int>(fact_a + 4u * k, ((const int32_t*)(a.blob + off_fact))[k]);
 
     // a workgroup walks groups of S consecutive samples (the last group of the batch may be short: its missing samples
     // repeat sample N - 1 -- same angles, same amplitudes, stored to the same place)
@@ -290,11 +248,11 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
     const int64_t s_begin = (int64_t)blockIdx.x * per_wg;
     const int64_t s_end = s_begin + per_wg < n_group ? s_begin + per_wg : n_group;
     const int wave_s = uni(tid0 >> 6);
-    // The angles of sample `smp` into buffer `buf`: wave w fetches the slots w, w + T/64, ... (64 angles per DMA
-    // instruction; lanes past the last angle re-read it).  my_nd = how many instructions that is for this wave: the
-    // number of memory operations it has in flight is known where it waits for them.
+    // What a group needs arrives by LDS-DMA, 64 pieces of 16 bytes per instruction, wave w issuing the instructions
+    // w, w + T / 64, ...: the angles of its per-thread terms (lanes past the last one re-read it) and one contiguous
+    // block of stage tables and matrices (the pre-pass kernels pad the batch to whole groups).
     auto share = [&](int slots) { const int k = (slots - wave_s + T / 64 - 1) / (T / 64); return k > 0 ? k : 0; };
-    const int my_na = share(n_slot / 64), my_nt = share((int)(dt_bytes >> 10));
+    const int my_na = share(n_slot / 64), my_ns = share((int)(side_bytes >> 10));
     auto fetch_angles = [&](int64_t smp, int buf, int lane) __attribute__((always_inline)) {      // smp: the group
         for (int j = 0; j < my_na; ++j) {
             const int slot = wave_s + j * (T / 64);
@@ -306,16 +264,15 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(size_t)dst, 16, 0, 0);
         }
     };
-    // the group's stage tables: one contiguous block (the table kernel pads the batch to whole groups)
-    auto fetch_tables = [&](int64_t smp, int buf, int lane) __attribute__((always_inline)) {
-        for (int j = 0; j < my_nt; ++j) {
+    auto fetch_side = [&](int64_t smp, int buf, int lane) __attribute__((always_inline)) {
+        for (int j = 0; j < my_ns; ++j) {
             const int slot = wave_s + j * (T / 64);
-            const double2* src = a.tabs + (smp * t_piece + min(slot * 64 + lane, t_piece - 1));
-            const uint32_t dst = dtab_a + (uint32_t)buf * dt_bytes + 1024u * (uint32_t)slot;
+            const double2* src = a.side + (smp * side_piece + min(slot * 64 + lane, side_piece - 1));
+            const uint32_t dst = side_a + (uint32_t)buf * side_bytes + 1024u * (uint32_t)slot;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(size_t)dst, 16, 0, 0);
         }
     };
-    if (s_begin < s_end) { fetch_angles(s_begin, 0, tid0 & 63); fetch_tables(s_begin, 0, tid0 & 63); }
+    if (s_begin < s_end) { fetch_angles(s_begin, 0, tid0 & 63); fetch_side(s_begin, 0, tid0 & 63); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
@@ -334,103 +291,68 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
         asm volatile("" : "+s"(ones));
         int tid = (wave_s << 6) | (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
         asm volatile("" : "+v"(tid));
-        // The next sample's angles travel while this one is computed.  This sample's were fetched one iteration ago:
-        // younger than them are that iteration's NA stores of Psi and the nd fetches just issued, and memory operations
-        // complete in order -- a counted wait, so the stores go on draining under this sample's arithmetic (a plain
-        // vmcnt(0), which is what a prefetch into registers gets from the compiler, holds the workgroup until the whole
-        // statevector of the previous sample has left the chip).
-        if (my_na > 8) {
-            // (many narrow samples per group: more fetches than a counted wait is written out for below -- wait for
-            // everything, then fetch; the stores of a group are a small part of its time there)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fetch_angles(sample + 1 < s_end ? sample + 1 : sample, it ^ 1, tid & 63);
-        } else {
-            // older than this: the group's angles, then its tables (fetched behind the barrier below, one iteration ago)
-            fetch_angles(sample + 1 < s_end ? sample + 1 : sample, it ^ 1, tid & 63);
-            if (my_na == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
-            else if (my_na == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 1) : "memory");
-            else if (my_na == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 2) : "memory");
-            else if (my_na == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 3) : "memory");
-            else if (my_na == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 4) : "memory");
-            else if (my_na == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 5) : "memory");
-            else if (my_na == 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 6) : "memory");
-            else if (my_na == 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 7) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 8) : "memory");
-        }
+        // This group's angles, tables and matrices were fetched one turn ago; younger than those fetches are only that
+        // turn's NA stores of Psi, and memory operations complete in order -- a counted wait, so the stores go on
+        // draining under this group's arithmetic (a plain vmcnt(0), which is what a prefetch into registers gets from the
+        // compiler, holds the workgroup until the whole statevector of the previous sample has left the chip).
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
         QK_RMARK(0);
-        lds_barrier();      // every wave's share of this sample's angles has landed; the previous sample is done with terms / matrices / tables
-        // only now may the next group's tables overwrite the buffer the previous group read in its last segment
-        if (tab_single) { if (sample > s_begin) fetch_tables(sample, 0, tid & 63); }      // (the first group's came before the loop)
-        else fetch_tables(sample + 1 < s_end ? sample + 1 : sample, it ^ 1, tid & 63);
+        lds_barrier();      // every wave's share of the fetch has landed; every wave is done with the previous group
         QK_RMARK(8);
-        for (int i = tid; i < n_expr * S; i += T) {
-            const v2d cs = ldsr<v2d>(cs_a + 16u * (uint32_t)(it * n_slot + i));
-            const int2v de = ldsr<int2v>(sexpr_a + 8u * (uint32_t)(i >> sbits));
-            const uint32_t so = (uint32_t)(i & (S - 1));
-            scatter_angle(de.x, de.y, cs.x, cs.y, rt_a + rt_s * so, mat_a + mat_s * so);
-        }
-        if (tab_single) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's tables, fetched a moment ago
-        lds_barrier();
-        QK_RMARK(9);
-        if (n_comp) {       // runs of single-qubit gates on one qubit: one thread multiplies a run's factors
-            for (int i = tid; i < n_comp * S; i += T) {
-                const int4v cc = ldsr<int4v>(comp_a + 16u * (uint32_t)(i >> sbits));       // dst, first, count
-                const uint32_t mat_i = mat_a + mat_s * (uint32_t)(i & (S - 1));
-                auto M = [&](int f, int j) { return ldsr<v2d>(mat_i + 64u * (uint32_t)f + 16u * j); };
-                const int f0 = ldsr<int>(fact_a + 4u * cc.y);
-                v2d m0 = M(f0, 0), m1 = M(f0, 1), m2 = M(f0, 2), m3 = M(f0, 3);
-                for (int j = 1; j < cc.z; ++j) {     // M <- G M
-                    const int f = ldsr<int>(fact_a + 4u * (cc.y + j));
-                    const v2d g0 = M(f, 0), g1 = M(f, 1), g2 = M(f, 2), g3 = M(f, 3);
-                    const v2d n0 = cmul(g0, m0) + cmul(g1, m2), n1 = cmul(g0, m1) + cmul(g1, m3);
-                    const v2d n2 = cmul(g2, m0) + cmul(g3, m2), n3 = cmul(g2, m1) + cmul(g3, m3);
-                    m0 = n0; m1 = n1; m2 = n2; m3 = n3;
-                }
-                const uint32_t d = mat_i + 64u * (uint32_t)cc.x;
-                ldsw<v2d>(d, m0); ldsw<v2d>(d + 16u, m1); ldsw<v2d>(d + 32u, m2); ldsw<v2d>(d + 48u, m3);
-            }
+        // The next group's data travel while this one is computed -- issued only now: the buffers they land in were read
+        // by the previous group up to its last segment.
+        const int64_t nxt = sample + 1 < s_end ? sample + 1 : sample;
+        fetch_angles(nxt, it ^ 1, tid & 63);
+        if (!side_single) {
+            fetch_side(nxt, it ^ 1, tid & 63);
+        } else if (sample > s_begin) {      // one buffer: this group's own tables and matrices, now (the first group's came before the loop)
+            fetch_side(sample, 0, tid & 63);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
         }
-        QK_RMARK(10);
+        const uint32_t side_i = side_a + (side_single ? 0u : (uint32_t)it * side_bytes);      // this group's tables, then its matrices
+        const uint32_t mats_i = side_i + ((uint32_t)t_piece << 4);
+        QK_RMARK(9);
         // ---- the tables of the product state, 16 entries each: products of the first columns of the first gates' matrices
         // (not needed when every first gate is a Hadamard; the tables of the diagonal stages arrive ready-made)
         // (PACK: a wave builds the tables of the samples wave, wave + T / 64, ... of the group, its lanes over the entries)
         if (n_ib) {
-        for (int so = PACK ? wave_s : 0; so < S; so += PACK ? T / 64 : 1) {
-        const uint32_t mat_i = mat_a + mat_s * (uint32_t)so, tab_i = itab_a + itab_s * (uint32_t)so;
-        for (int e = PACK ? (tid & 63) : tid; e < 16 * n_ib; e += PACK ? 64 : T) {
-            const uint32_t tb = stab_a + 32u * (uint32_t)(e >> 4);      // bits[4], nbits, fixed, t0 (mask of extra qubits), nt < 0
-            const int4v bits = ldsr<int4v>(tb), rest = ldsr<int4v>(tb + 16u);
-            const int nbits = rest.x, t0 = rest.z;
-            const uint32_t x = (uint32_t)e & 15u;
-            v2d f = (v2d){1.0, 0.0};
-            auto column = [&](int q, uint32_t bit) {
-                const int m = ldsr<int>(init_a + 4u * q);
-                const v2d u = ldsr<v2d>(mat_i + 64u * (uint32_t)(m < 0 ? 0 : m) + 32u * bit);
-                return m < 0 ? (v2d){bit ? 0.0 : 1.0, 0.0} : u;
-            };
-            if (nbits > 0) f = cmul(f, column(bits.x, x & 1u));
-            if (nbits > 1) f = cmul(f, column(bits.y, (x >> 1) & 1u));
-            if (nbits > 2) f = cmul(f, column(bits.z, (x >> 2) & 1u));
-            if (nbits > 3) f = cmul(f, column(bits.w, (x >> 3) & 1u));
-            for (uint32_t m = (uint32_t)t0; m; m &= m - 1u) {      // the extra high thread qubits of this slot (their values: fixed)
-                const int q = __builtin_ctz(m);
-                f = cmul(f, column(q, ((uint32_t)rest.y >> q) & 1u));
+            for (int so = PACK ? wave_s : 0; so < S; so += PACK ? T / 64 : 1) {
+                const uint32_t mat_i = mats_i + mat_s * (uint32_t)so, tab_i = itab_a + itab_s * (uint32_t)so;
+                for (int e = PACK ? (tid & 63) : tid; e < 16 * n_ib; e += PACK ? 64 : T) {
+                    const uint32_t tb = stab_a + 32u * (uint32_t)(e >> 4);      // bits[4], nbits, fixed, t0 (mask of extra qubits), nt < 0
+                    const int4v bits = ldsr<int4v>(tb), rest = ldsr<int4v>(tb + 16u);
+                    const int nbits = rest.x, t0 = rest.z;
+                    const uint32_t x = (uint32_t)e & 15u;
+                    v2d f = (v2d){1.0, 0.0};
+                    auto column = [&](int q, uint32_t bit) {
+                        const int m = ldsr<int>(init_a + 4u * q);
+                        const v2d u = ldsr<v2d>(mat_i + 64u * (uint32_t)(m < 0 ? 0 : m) + 32u * bit);
+                        return m < 0 ? (v2d){bit ? 0.0 : 1.0, 0.0} : u;
+                    };
+                    if (nbits > 0) f = cmul(f, column(bits.x, x & 1u));
+                    if (nbits > 1) f = cmul(f, column(bits.y, (x >> 1) & 1u));
+                    if (nbits > 2) f = cmul(f, column(bits.z, (x >> 2) & 1u));
+                    if (nbits > 3) f = cmul(f, column(bits.w, (x >> 3) & 1u));
+                    for (uint32_t m = (uint32_t)t0; m; m &= m - 1u) {      // the extra high thread qubits of this slot (their values: fixed)
+                        const int q = __builtin_ctz(m);
+                        f = cmul(f, column(q, ((uint32_t)rest.y >> q) & 1u));
+                    }
+                    if ((int)x >= (1 << nbits)) f = (v2d){1.0, 0.0};
+                    ldsw<v2d>(tab_i + 16u * e, f);
+                }
             }
-            if ((int)x >= (1 << nbits)) f = (v2d){1.0, 0.0};
-            ldsw<v2d>(tab_i + 16u * e, f);
+            lds_barrier();
         }
-        }
-        }
-        lds_barrier();
         QK_RMARK(11);
 
         v2d v[NA];
         double scale = 1.0;
         // this lane's sample of the group and where its terms, matrices and tables are
         const uint32_t sid = PACK ? (uint32_t)tid >> (nq - RB) : 0u;
-        const uint32_t rt_l = PACK ? rt_a + rt_s * sid : rt_a, mat_l = PACK ? mat_a + mat_s * sid : mat_a;
-        const uint32_t itab_l = PACK ? itab_a + itab_s * sid : itab_a, dtab_l = dtab_a + (tab_single ? 0u : (uint32_t)it * dt_bytes) + (PACK ? dtab_s * sid : 0u);
+        const uint32_t mat_l = PACK ? mats_i + mat_s * sid : mats_i, dtab_l = PACK ? side_i + dtab_s * sid : side_i;
+        const uint32_t itab_l = PACK ? itab_a + itab_s * sid : itab_a;
+        const uint32_t cs_l = cs_a + 16u * ((uint32_t)(it * n_slot) + sid);      // angle e of this lane's sample: + (e << sbits) pairs
         const int n_lo = nq - RB < 4 ? nq - RB : 4, n_hi = nq - RB - n_lo;      // thread qubits behind the two thread tables (n_hi > 4: second slot)
         for (int sg = 0; sg < n_seg; ++sg) {
             // the segment record: 16 words, one scalar load
@@ -533,10 +455,10 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                         const bool fresh = (o_flags & 256) != 0;      // the state is the identity times the running scale: write, do not multiply
                         bt = (v2d){bt.x * scale, bt.y * scale};
                         scale = 1.0;
-                        for (int k = 0; k < nTX; ++k) bt = cmul(bt, term_factor(term_at(rt_l, t0 + k), wt));
+                        for (int k = 0; k < nTX; ++k) bt = cmul(bt, term_factor(term_at(rts_a, cs_l, sbits, t0 + k), wt));
                         v2d r0 = (v2d){1.0, 0.0}, r1 = r0, r2 = r0, r3 = r0;
                         for (int k = 0; k < nRT; ++k) {
-                            const TermL t = term_at(rt_l, t0 + nTX + k);
+                            const TermL t = term_at(rts_a, cs_l, sbits, t0 + nTX + k);
                             const int rp = uni(t.rpos);
                             const uint32_t gb = rp == 0 ? 1u << g0 : (rp == 1 ? 1u << g1 : (rp == 2 ? 1u << g2 : 1u << g3));
                             const v2d f0 = term_factor(t, wt), f1 = term_factor(t, wt | gb);
@@ -632,15 +554,29 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
 #endif
 }
 
-// The phase tables of the diagonal stages, for every sample of the batch: one thread per (sample, table), the samples of a
-// wave consecutive.  Which entries of a table take a term's factor (or its conjugate) is the same for every sample --
-// two 16-bit masks per (table, term) from the planner -- so the threads of a wave run one instruction stream of
-// coalesced angle loads and complex multiplications, without a select: inside the simulator the same products were one
-// lane per ENTRY of ONE sample, each a chain of LDS reads and selects (a fifth of a 12-qubit sample's time, most of an
-// 8-qubit one's).  The batch is padded to whole groups of 2^(L - nq) samples with copies of the last sample.
+// ---- pre-pass: what a sample needs beside its amplitudes, for every sample of the batch ---------------------------
+// Layout of the result (RegArgs::side): per group of S = 2^(L - nq) samples one contiguous block -- S x n_dtab tables of 16
+// entries, then S x n_mat matrices of 4 entries -- which the simulator fetches with LDS-DMA as it is.  The batch is
+// padded to whole groups with copies of the last sample.
+struct SideShape { int sb, n_dtab, n_mat; int64_t piece; };      // piece: 16-byte entries per group
+__device__ __forceinline__ SideShape side_shape(CWords hw) {
+    SideShape s;
+    s.sb = hw[0] - hw[21];
+    s.n_dtab = hw[3] - hw[24];
+    s.n_mat = hw[6];
+    s.piece = ((int64_t)(s.n_dtab * 16 + s.n_mat * 4)) << s.sb;
+    return s;
+}
+
+// The phase tables of the diagonal stages: one thread per (sample, table), the samples of a wave consecutive.  Which
+// entries of a table take a term's factor (or its conjugate) is the same for every sample -- two 16-bit masks per
+// (table, term) from the planner -- so the threads of a wave run one instruction stream of coalesced angle loads and
+// complex multiplications, without a select: inside the simulator the same products were one lane per ENTRY of ONE
+// sample, each a chain of LDS reads and selects (a fifth of a 12-qubit sample's time, most of an 8-qubit one's).
 __global__ void __launch_bounds__(256) reg_table_kernel(const char* blob, const double2* cs, int64_t N, int64_t n_pad, double2* out) {
     const CWords hw = cwords(blob);
-    const int n_itab = hw[24], n_dtab = hw[3] - hw[24];
+    const SideShape sh = side_shape(hw);
+    const int n_itab = hw[24];
     const int table = blockIdx.y;
     const int64_t sample = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (sample >= n_pad) return;
@@ -664,27 +600,73 @@ __global__ void __launch_bounds__(256) reg_table_kernel(const char* blob, const 
         for (int x = 0; x < 16; ++x)
             if ((masks >> x) & 1u) f[x] = cmul(f[x], ((masks >> (16 + x)) & 1u) ? uc : u);      // wave-uniform tests
     }
-    v2d* o = (v2d*)out + ((sample * n_dtab + table) << 4);
+    const int64_t s_in = sample & (((int64_t)1 << sh.sb) - 1);
+    v2d* o = (v2d*)out + (sample >> sh.sb) * sh.piece + ((s_in * sh.n_dtab + table) << 4);
 #pragma unroll
     for (int x = 0; x < 16; ++x) o[x] = f[x];
 }
 
-// bytes of the stage tables of a batch of N samples (0: the circuit has no diagonal stage)
+// The 2x2 matrices the simulator applies (single gates and runs of gates on one qubit, multiplied out): one thread per
+// (sample, matrix), uniform control flow per wave as above.
+__global__ void __launch_bounds__(256) reg_matrix_kernel(const char* blob, const double2* cs, int64_t N, int64_t n_pad, double2* out) {
+    const CWords hw = cwords(blob);
+    const SideShape sh = side_shape(hw);
+    const int u_i = blockIdx.y;
+    const int64_t sample = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sample >= n_pad) return;
+    const int64_t src = sample < N ? sample : N - 1;
+    const CWords rec = cwords(blob + hw[15]) + 2 * u_i;
+    const int first = rec[0], count = rec[1];
+    const CWords fc = cwords(blob + hw[17]) + 2 * first;
+    v2d m0 = (v2d){1, 0}, m1 = (v2d){0, 0}, m2 = (v2d){0, 0}, m3 = (v2d){1, 0};
+    for (int k = 0; k < count; ++k) {
+        const int gate = fc[2 * k], expr = fc[2 * k + 1];
+        double cn = 1.0, sn = 0.0;
+        if (expr >= 0) {
+            const double2 g = cs[(int64_t)expr * N + src];
+            cn = g.x; sn = g.y;
+        }
+        const double r = 0.70710678118654752440;
+        v2d g0, g1, g2, g3;
+        if (gate == QK_H) { g0 = (v2d){r, 0}; g1 = (v2d){r, 0}; g2 = (v2d){r, 0}; g3 = (v2d){-r, 0}; }
+        else if (gate == QK_X) { g0 = (v2d){0, 0}; g1 = (v2d){1, 0}; g2 = (v2d){1, 0}; g3 = (v2d){0, 0}; }
+        else if (gate == QK_SX) { g0 = (v2d){0.5, 0.5}; g1 = (v2d){0.5, -0.5}; g2 = (v2d){0.5, -0.5}; g3 = (v2d){0.5, 0.5}; }
+        else if (gate == QK_RX) { g0 = (v2d){cn, 0}; g1 = (v2d){0, -sn}; g2 = (v2d){0, -sn}; g3 = (v2d){cn, 0}; }
+        else if (gate == QK_RZ) { g0 = (v2d){cn, -sn}; g1 = (v2d){0, 0}; g2 = (v2d){0, 0}; g3 = (v2d){cn, sn}; }
+        else if (gate == QK_P) { g0 = (v2d){1, 0}; g1 = (v2d){0, 0}; g2 = (v2d){0, 0}; g3 = (v2d){cn, sn}; }
+        else { g0 = (v2d){cn, 0}; g1 = (v2d){-sn, 0}; g2 = (v2d){sn, 0}; g3 = (v2d){cn, 0}; }      // ry
+        if (k == 0) { m0 = g0; m1 = g1; m2 = g2; m3 = g3; }
+        else {      // M <- G M
+            const v2d n0 = cmul(g0, m0) + cmul(g1, m2), n1 = cmul(g0, m1) + cmul(g1, m3);
+            const v2d n2 = cmul(g2, m0) + cmul(g3, m2), n3 = cmul(g2, m1) + cmul(g3, m3);
+            m0 = n0; m1 = n1; m2 = n2; m3 = n3;
+        }
+    }
+    const int64_t s_in = sample & (((int64_t)1 << sh.sb) - 1);
+    v2d* o = (v2d*)out + (sample >> sh.sb) * sh.piece + (((int64_t)sh.n_dtab << sh.sb) << 4) + ((s_in * sh.n_mat + u_i) << 2);
+    o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m3;
+}
+
+// bytes of the tables and matrices of a batch of N samples (0: the circuit has neither)
 size_t reg_table_bytes(const qk_circuit& c, int64_t N) {
     const RegHeader* H = (const RegHeader*)c.reg_blob.data();
     const int sb = H->L - H->nq;
-    const int64_t n_pad = ((N + ((int64_t)1 << sb) - 1) >> sb) << sb;
-    return (size_t)n_pad * (size_t)(H->n_tab - H->n_itab) * 256;
+    const int64_t n_group = (N + ((int64_t)1 << sb) - 1) >> sb;
+    return (size_t)n_group * ((size_t)((H->n_tab - H->n_itab) * 16 + H->n_mat * 4) << sb) * 16;
 }
 
 int launch_reg_tables(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* tabs, hipStream_t stream) {
     const RegHeader* H = (const RegHeader*)c.reg_blob.data();
     const int n_dtab = H->n_tab - H->n_itab, sb = H->L - H->nq;
-    if (n_dtab <= 0 || N <= 0) return QK_OK;
+    if (N <= 0) return QK_OK;
     const int64_t n_pad = ((N + ((int64_t)1 << sb) - 1) >> sb) << sb;
     if ((n_pad + 255) / 256 > 0x7fffffff) return fail(QK_ERR_UNSUPPORTED, "register-resident simulator: batch too large");
-    hipLaunchKernelGGL(reg_table_kernel, dim3((unsigned)((n_pad + 255) / 256), (unsigned)n_dtab), dim3(256), 0, stream,
-                       (const char*)blob_dev, cs, N, n_pad, (double2*)tabs);
+    if (n_dtab > 0)
+        hipLaunchKernelGGL(reg_table_kernel, dim3((unsigned)((n_pad + 255) / 256), (unsigned)n_dtab), dim3(256), 0, stream,
+                           (const char*)blob_dev, cs, N, n_pad, (double2*)tabs);
+    if (H->n_mat > 0)
+        hipLaunchKernelGGL(reg_matrix_kernel, dim3((unsigned)((n_pad + 255) / 256), (unsigned)H->n_mat), dim3(256), 0, stream,
+                           (const char*)blob_dev, cs, N, n_pad, (double2*)tabs);
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
@@ -709,7 +691,7 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
     RegArgs a{};
     a.blob = (const char*)blob_dev;
     a.cs = cs;
-    a.tabs = (const double2*)tabs;
+    a.side = (const double2*)tabs;
     a.N = N;
     a.psi = (double2*)psi;
     a.psi32 = (float2*)psi32;
@@ -741,7 +723,7 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
             for (int k = 0; k < 12; ++k) sum[k] += h[12 * b + k];
         std::fprintf(stderr, "[reg trace] L=%d nq=%d RB=%d blocks=%lld groups=%.0f us per sample group and workgroup:", L, H->nq, RB, (long long)nblocks, sum[7]);
         const char* names[12] = {"wait for angles", "segment setup", "transpose read", "init/diag ops", "u1 ops", "other ops", "transpose write / stores", "",
-                                 "barrier", "scatter", "composites", "tables"};
+                                 "barrier", "issue next fetch", "-", "product-state tables"};
         for (int k = 0; k < 12; ++k)
             if (k != 7) std::fprintf(stderr, " %s %.2f", names[k], sum[k] / sum[7] * 0.01);
         std::fprintf(stderr, "\n");

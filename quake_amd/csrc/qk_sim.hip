@@ -1273,24 +1273,25 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     const bool big = (N >> 22 >> 0) != 0 || (N << n) >= ((int64_t)1 << 22);
     const bool prefer_lds = !force_wave && (big || n > kWaveMaxQubits) && ((direct_shape && (n >= 9 || (n >= 6 && all_h_init(c.passes[0])))) ||
                                             (n >= 6 && h_layers_shape()));
-    // 10 to 13 qubits in one pass with butterflies or swaps to do: the register-resident kernel (qk_reg.hip).  A circuit
-    // that is the product state and ONE diagonal stage stays on the direct-store pass below (nothing to keep in
-    // registers: it writes every amplitude once).  QK_SIM_PATH=reg sends every circuit that has such a plan there,
-    // QK_SIM_PATH=noreg none (A/B runs).
+    // The register-resident kernel (qk_reg.hip), for circuits that have such a plan (4 to 13 qubits, one pass):
+    //   11 to 13 qubits: whenever there are butterflies or swaps to do -- a circuit that is the product state and ONE
+    //     diagonal stage stays on the direct-store pass below (nothing to keep in registers: it writes every amplitude once);
+    //   up to 10 qubits: every circuit, once the batch fills the chip with groups of samples (tools/sim_bench.py, round 3:
+    //     8 qubits ZZ r=1 2.30 -> 1.48 ms, r=2 5.23 -> 2.48 ms per 4 GiB); small batches stay on the wave-resident
+    //     kernel, which is one launch instead of three or four.
+    // QK_SIM_PATH=reg sends every circuit that has a plan there, QK_SIM_PATH=noreg none (A/B runs).
     static const int reg_mode = [] {
         const char* e = std::getenv("QK_SIM_PATH");
         return !e ? 0 : (std::strcmp(e, "reg") == 0 ? 1 : (std::strcmp(e, "noreg") == 0 || std::strcmp(e, "lds") == 0 || std::strcmp(e, "wave") == 0 ? -1 : 0));
     }();
-    // Below 10 qubits the plan packs several samples into a workgroup; it takes over from the wave-resident kernel
-    // once the batch is large enough to fill the chip with such groups (small batches: one launch less there).
-    const bool reg_pays = n >= 11 || (n < kRegMinQubits && (N << n) >= ((int64_t)1 << 21));
-    if (dt.reg && !rdm_dev && reg_mode >= 0 && (reg_mode > 0 || (!direct_shape && reg_pays))) {
+    const bool reg_pays = n >= 11 ? !direct_shape : big;
+    if (dt.reg && !rdm_dev && reg_mode >= 0 && (reg_mode > 0 || reg_pays)) {
         const RegHeader* H = (const RegHeader*)c.reg_blob.data();
         // The angles and the stage tables of the batch live in stream order.  Large batches go in chunks of whole sample
-        // groups so that those two tables stay within 256 MiB whatever N is.
-        const int64_t per_sample = (int64_t)H->n_expr * 16 + (int64_t)(H->n_tab - H->n_itab) * 256;
+        // groups so that those tables stay within 1 GiB whatever N is.
+        const int64_t per_sample = (int64_t)H->n_expr * 16 + (int64_t)(H->n_tab - H->n_itab) * 256 + (int64_t)H->n_mat * 64;
         const int64_t group = (int64_t)1 << (H->L - H->nq);
-        int64_t chunk = per_sample > 0 ? std::max<int64_t>(((int64_t)256 << 20) / per_sample, 65536) : N;
+        int64_t chunk = per_sample > 0 ? std::max<int64_t>(((int64_t)1 << 30) / per_sample, 65536) : N;
         chunk = std::min<int64_t>(N, chunk / group * group);
         for (int64_t s0 = 0; s0 < N; s0 += chunk) {
             const int64_t Nc = std::min(chunk, N - s0);

@@ -260,7 +260,7 @@ def test_register_resident_simulator_many_samples(n, seed, N):
     del psi, psi32
 
 
-@pytest.mark.parametrize("n,seed,N,gates", [(4, 30, 131072 + 37, 8), (5, 31, 65536 + 5, 16), (6, 32, 40000 + 1, 54), (7, 33, 20000 + 3, 63),
+@pytest.mark.parametrize("n,seed,N,gates", [(4, 30, 131072 + 37, 8), (5, 31, 65536 + 5, 12), (6, 32, 40000 + 1, 16), (7, 33, 20000 + 3, 63),
                                             (8, 34, 9000 + 7, 72), (9, 35, 4096 + 1, 81)])
 def test_register_resident_simulator_packed_samples(n, seed, N, gates):
     """4 to 9 qubits: several samples share a workgroup of the register-resident kernel (index bits above the circuit's
