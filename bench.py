@@ -182,7 +182,7 @@ def pmc_traffic_committed(N, n, repeats, world):
     """HBM bytes per Gram launch from the committed PMC passes (profiles/), when this is the workload
     they were taken on.  NOT a measurement of this run (that is why `roofline.traffic` stays null);
     collected per the guide (separate --pmc passes, FETCH_SIZE x2)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:

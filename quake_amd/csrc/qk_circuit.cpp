@@ -608,7 +608,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     // layout and no gate touches them, so one instruction stream (segments, ops, transposes) serves all those samples
     // and only the angles, matrices and phase tables exist once per sample.
     c.reg_blob.clear();
-    auto plan_reg = [&](const int Lv, const size_t lds_limit) -> bool {
+    auto plan_reg = [&](const int Lv, const size_t lds_limit, size_t* dry_lds = nullptr) -> bool {      // dry_lds: only report the LDS a workgroup would need
         // Single-qubit gates on distinct qubits with nothing between them commute: inside such a run the gates are
         // taken in ascending qubit order, so that a layer of gates fills whole groups of four neighbouring qubits and
         // the groups with the low qubits come first (the last layout then keeps the low qubits in the thread index:
@@ -895,6 +895,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         const size_t nd = (n_slot / 64 + waves - 1) / waves + (t_slot + waves - 1) / waves;    // fetch instructions per wave and sample group
         if (std::getenv("QK_REG_DEBUG")) std::fprintf(stderr, "[reg plan] Lv=%d fits=%d nd=%zu lds=%zu limit=%zu tabs=%zu terms=%zu mats=%zu\n", Lv, (int)fits, nd, lds, lds_limit, tabs.size(), rterms.size(), rmats.size());
         if (!(fits && nd <= 64 && lds <= lds_limit)) return false;
+        if (dry_lds) { *dry_lds = all_h ? lds : (lds | ((size_t)1 << 40)); return true; }      // (bit 40: product-state tables are built in the kernel)
         {
             auto pad16 = [](size_t b) { return (b + 15) / 16 * 16; };
             RegHeader H{};
@@ -941,12 +942,24 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1 && c.passes[0].L == n) {
         plan_reg(n, (size_t)160 * 1024);
     } else if (n >= kRegPackMinQubits && n < kRegMinQubits && c.passes.size() == 1 && c.passes[0].L == n) {
-        // the widest workgroup that leaves room for two per CU, else the narrowest that fits at all; QK_REG_LV forces one (A/B runs)
+        // The width that keeps the most waves resident on a CU (LDS per workgroup against 2 waves per SIMD at 247 VGPRs);
+        // among equals the narrowest workgroup, whose barriers cost least (9 qubits, GA genome: 3.9 ms at L = 10 with five
+        // waves per CU, 5.1 at L = 11 and 4.3 at L = 12 with four; 8 qubits ZZ r = 2: 2.5 / 2.5 / 2.8 ms with 6 / 6 / 4).
+        // QK_REG_LV forces one (A/B runs).
         static const int lv_env = std::getenv("QK_REG_LV") ? std::atoi(std::getenv("QK_REG_LV")) : 0;
         bool done = false;
         if (lv_env >= kRegMinQubits && lv_env <= kRegPackMaxWidth) done = plan_reg(lv_env, (size_t)160 * 1024);
-        for (int Lv = kRegPackMaxWidth; Lv >= kRegMinQubits && !done; --Lv) done = plan_reg(Lv, (size_t)80 * 1024);
-        for (int Lv = kRegMinQubits; Lv <= kRegPackMaxWidth && !done; ++Lv) done = plan_reg(Lv, (size_t)160 * 1024);
+        int best = 0, best_waves = 0;
+        for (int Lv = kRegMinQubits; Lv <= kRegPackMaxWidth && !done; ++Lv) {
+            size_t lds = 0;
+            if (!plan_reg(Lv, (size_t)160 * 1024, &lds)) continue;
+            // a first layer that is not all Hadamards (GA genomes) has its product-state tables built inside the kernel, a
+            // wave per sample and a barrier behind it: single-wave workgroups (L = 10) keep that wave-local
+            if ((lds >> 40) & 1) { best = Lv; break; }
+            const int waves = std::min(8, (int)((size_t)160 * 1024 / lds) * ((1 << (Lv - 4)) / 64));
+            if (waves > best_waves) { best_waves = waves; best = Lv; }
+        }
+        if (!done && best) plan_reg(best, (size_t)160 * 1024);
     }
     return QK_OK;
 }
