@@ -940,7 +940,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         return true;
     };
     if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1 && c.passes[0].L == n) {
-        plan_reg(n, (size_t)160 * 1024);
+        // (QK_REG_LV = 12 at 10 or 11 qubits: four or two samples per workgroup of 256 threads, A/B runs)
+        static const int lv_wide = std::getenv("QK_REG_LV") ? std::atoi(std::getenv("QK_REG_LV")) : 0;
+        if (!(lv_wide > n && lv_wide <= kRegPackMaxWidth && plan_reg(lv_wide, (size_t)160 * 1024))) plan_reg(n, (size_t)160 * 1024);
     } else if (n >= kRegPackMinQubits && n < kRegMinQubits && c.passes.size() == 1 && c.passes[0].L == n) {
         // The width that keeps the most waves resident on a CU (LDS per workgroup against 2 waves per SIMD at 247 VGPRs);
         // among equals the narrowest workgroup, whose barriers cost least (9 qubits, GA genome: 3.9 ms at L = 10 with five

@@ -286,6 +286,24 @@ def test_register_resident_simulator_packed_samples(n, seed, N, gates):
         assert np.abs(dc.simulate(Xd[:small].contiguous()).cpu().numpy() - ref[:small]).max() < TOL_PSI
 
 
+def test_register_resident_simulator_in_chunks():
+    """A batch whose pre-pass tables would exceed 1 GiB goes through the register-resident path in chunks of whole sample
+    groups (6 qubits, ZZ r = 2: 1376 bytes of angles and tables per sample, 800 003 samples = a chunk of 2^30 / 1376 samples rounded down to whole groups and the rest, the second one
+    ending in a short group); rows sampled from both chunks and around the seam against the oracle, every row's norm."""
+    import torch
+    from quake_amd import device as qdev
+    n, N = 6, 800003
+    circ, oops, _ = map_pairs(n, 2)["zz"]
+    assert "register-resident plan" in HipFidelityKernel(circ)._circuit().plan_summary
+    X = synth_X(N, n, "scaled", 77)
+    psi = qdev.DeviceCircuit(circ).simulate(torch.from_numpy(X).cuda())
+    rows = np.unique(np.concatenate([[0, 1, N - 2, N - 1], np.arange(780200, 780400), np.random.default_rng(5).integers(0, N, 200)]))
+    got = psi[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert np.abs(got - O.statevectors(oops, n, X[rows])).max() < TOL_PSI
+    assert float(((psi.real ** 2 + psi.imag ** 2).sum(dim=1) - 1.0).abs().max()) < 1e-12
+    del psi
+
+
 @pytest.mark.parametrize("n,seed", [(1, 0), (3, 1), (7, 2), (10, 3), (11, 4), (12, 5), (14, 6)])
 def test_statevectors_single_qubit_runs(n, seed):
     """Long runs of single-qubit gates on one qubit between rare two-qubit gates (the shape of a GA genome
