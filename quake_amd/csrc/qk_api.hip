@@ -289,12 +289,20 @@ int gram_to_host(const void* dPx, int64_t N, const void* dPy, int64_t M, int64_t
     // while a launch runs the closer to the rate of one big job the larger its blocks are: sixteen equal bands cost
     // 4.4 % over a single launch at the headline size (the rows of a late band are short symmetric blocks next to
     // a sliver of a cross block), about what their overlapped copies saved; six halving bands cost well under 1 %.
+    // (Short rows -- under 11 qubits the copy of K takes longer than computing it, 57 GB/s against 8 D flops per entry --
+    // keep sixteen equal bands: there the first band is what no copy overlaps.)
     std::vector<int64_t> cut{0};
-    while (N - cut.back() >= 2048 && cut.size() < 6) {
-        const int64_t take = ((N - cut.back()) / 2 + 127) / 128 * 128;
-        if (take < 1024 || N - cut.back() - take < 1024) break;
-        cut.push_back(cut.back() + take);
-        if (N - cut.back() <= std::max<int64_t>(1024, N / 32)) break;
+    if (D >= 2048) {
+        while (N - cut.back() >= 2048 && cut.size() < 6) {
+            const int64_t take = ((N - cut.back()) / 2 + 127) / 128 * 128;
+            if (take < 1024 || N - cut.back() - take < 1024) break;
+            cut.push_back(cut.back() + take);
+            if (N - cut.back() <= std::max<int64_t>(1024, N / 32)) break;
+        }
+    } else {
+        const int64_t nb = std::min<int64_t>(16, N / 1024);
+        const int64_t band = nb >= 2 ? ((N + nb - 1) / nb + 127) / 128 * 128 : N;
+        while (N - cut.back() > band) cut.push_back(cut.back() + band);
     }
     cut.push_back(N);
     const int64_t nbands = (int64_t)cut.size() - 1;

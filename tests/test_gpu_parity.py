@@ -632,11 +632,12 @@ def test_projected_kernel_distance_scales():
         assert np.array_equal(K, K.T)
 
 
-@pytest.mark.parametrize("precision,tol", [("double", TOL_K), ("single", 1e-5)])
-def test_host_path_row_bands(precision, tol):
+@pytest.mark.parametrize("precision,tol,n,N", [("double", TOL_K, 5, 3300), ("single", 1e-5, 5, 3300), ("double", TOL_K, 11, 5000)])
+def test_host_path_row_bands(precision, tol, n, N):
     """Above 2048 rows the host entry point computes K in row bands and copies each band back while
-    the next one is computed: symmetric (mirror entries come from earlier bands) and cross blocks."""
-    n, N, M = 5, 3300, 700
+    the next one is computed: symmetric (mirror entries come from earlier bands) and cross blocks.  Short rows: equal
+    bands (3300 rows = 3 bands); from 11 qubits on the bands halve (5000 rows = 2560 + 1280 + 1160)."""
+    M = 700
     circ, oops, _ = map_pairs(n, 1)["zz"]
     X, Y = synth_X(N, n, "scaled", 77), synth_X(M, n, "scaled", 78)
     k = HipFidelityKernel(circ, precision=precision)
