@@ -661,9 +661,12 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         std::vector<RegTerm> rterms;      // terms the simulator evaluates per thread (between two thread bits, or a register and a thread bit)
         struct TabTerm { int type, va, vb, tag; };
         std::vector<TabTerm> tterms;      // terms that live in a phase table (reg_table_kernel)
-        // DevExpr::dst of an angle that only a pre-pass kernel reads: a table term (DevExpr::gate = its tterm) or a factor of
-        // a matrix (DevExpr::gate = its RegFact); every other dst is a term of `rterms`
-        constexpr int kTabDst = 0x7fffffff, kMatDst = 0x7ffffffe;
+        // DevExpr::dst of an angle that only the pre-pass kernels read (table terms, factors of matrices; DevExpr::gate = its
+        // entry in pre_users); every other dst is a term of `rterms`.  Equal angles (the same program at the same scale:
+        // every repetition of a map re-uses the angles of the first) are evaluated once.
+        constexpr int kPreDst = 0x7fffffff;
+        struct PreUser { bool table; int index; };
+        std::vector<std::vector<PreUser>> pre_users;
         int n_itab = 0;
         std::vector<DevExpr> rexprs;
         std::vector<RegMat> rmats;        // the matrices the simulator reads, as products of factors (reg_matrix_kernel)
@@ -672,9 +675,20 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         auto r_expr = [&](int e, double scale, int dst, int gate = 0) {
             rexprs.push_back(DevExpr{expr_off[e], expr_off[e + 1] - expr_off[e], scale, dst, gate});
         };
+        auto r_pre = [&](int e, double scale, PreUser user) {
+            const int start = expr_off[e], len = expr_off[e + 1] - expr_off[e];
+            for (const DevExpr& x : rexprs) {
+                if (x.dst != kPreDst || x.len != len || x.scale != scale) continue;
+                bool same = true;
+                for (int k = 0; k < len && same; ++k) same = c.prog[x.start + k].op == c.prog[start + k].op && c.prog[x.start + k].arg == c.prog[start + k].arg;
+                if (same) { pre_users[x.gate].push_back(user); return; }
+            }
+            pre_users.push_back({user});
+            r_expr(e, scale, kPreDst, (int)pre_users.size() - 1);
+        };
         auto r_factor = [&](int gate, int expr) {
             rfacts.push_back(RegFact{gate, -1});
-            if (expr >= 0) r_expr(expr, gate == QK_P ? 1.0 : 0.5, kMatDst, (int)rfacts.size() - 1);
+            if (expr >= 0) r_pre(expr, gate == QK_P ? 1.0 : 0.5, PreUser{false, (int)rfacts.size() - 1});
         };
         auto r_matrix = [&](const Item& g) {
             RegMat m{(int)rfacts.size(), 1};
@@ -774,7 +788,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                             tterms.push_back(TabTerm{t.kind, t.q0, t.q1 >= 0 ? t.q1 : 0, -1});
                             if (t.expr >= 0) {
                                 tterms.back().tag = (int)tterms.size() - 1;
-                                r_expr(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, kTabDst, (int)tterms.size() - 1);
+                                r_pre(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, PreUser{true, (int)tterms.size() - 1});
                             }
                         }
                     }
@@ -844,7 +858,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             for (int k = 0; k < e.len; ++k) hsh = (hsh ^ (uint64_t)(c.prog[e.start + k].op + 1)) * 1099511628211ull;
             return hsh ^ (uint64_t)e.len;
         };
-        auto pre_only = [&](const DevExpr& e) { return e.dst == kTabDst || e.dst == kMatDst; };
+        auto pre_only = [&](const DevExpr& e) { return e.dst == kPreDst; };
         std::stable_sort(rexprs.begin(), rexprs.end(), [&](const DevExpr& x, const DevExpr& y) {
             if (pre_only(x) != pre_only(y)) return pre_only(y);
             if (x.len != y.len) return x.len > y.len;
@@ -853,9 +867,12 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         size_t n_expr_k = 0;
         std::vector<int32_t> term_expr(rterms.size(), -1);
         for (size_t e = 0; e < rexprs.size(); ++e) {      // where the terms and factors find their (cos, sin)
-            if (rexprs[e].dst == kTabDst) tterms[rexprs[e].gate].tag = (int)e;
-            else if (rexprs[e].dst == kMatDst) rfacts[rexprs[e].gate].expr = (int)e;
-            else { term_expr[rexprs[e].dst] = (int)e; n_expr_k = e + 1; }
+            if (rexprs[e].dst == kPreDst) {
+                for (const PreUser& u : pre_users[rexprs[e].gate]) (u.table ? tterms[u.index].tag : rfacts[u.index].expr) = (int)e;
+            } else {
+                term_expr[rexprs[e].dst] = (int)e;
+                n_expr_k = e + 1;
+            }
         }
         for (size_t t = 0; t < rterms.size(); ++t) rterms[t].expr = term_expr[t];
         // the table kernel's records: which entries of a table take a term's factor, which its conjugate
@@ -957,8 +974,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             if (!plan_reg(Lv, (size_t)160 * 1024, &lds)) continue;
             // a first layer that is not all Hadamards (GA genomes) has its product-state tables built inside the kernel, a
             // wave per sample and a barrier behind it: single-wave workgroups (L = 10) keep that wave-local
-            if ((lds >> 40) & 1) { best = Lv; break; }
-            const int waves = std::min(8, (int)((size_t)160 * 1024 / lds) * ((1 << (Lv - 4)) / 64));
+            if (((lds >> 40) & 1) && n >= 7) { best = Lv; break; }      // (6 qubits and below: 16+ samples per wave either way, the count decides)
+            const int waves = std::min(8, (int)((size_t)160 * 1024 / (lds & (((size_t)1 << 40) - 1))) * ((1 << (Lv - 4)) / 64));
             if (waves > best_waves) { best_waves = waves; best = Lv; }
         }
         if (!done && best) plan_reg(best, (size_t)160 * 1024);

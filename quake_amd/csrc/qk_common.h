@@ -220,9 +220,10 @@ size_t wave_lds_bytes(const qk_circuit& c);   // the (cos, sin) table of one uni
 int launch_wave_jobs(const WaveJob* jobs_host, int n_jobs, const WaveJob* table_dev, int nreg, int64_t total_units,
                      size_t cs_bytes, hipStream_t stream);
 // qk_reg.hip: the register-resident simulator (cs: the (cos, sin) table of the blob's angle programs, [expr][sample])
-//             tabs: the phase tables of its diagonal stages (launch_reg_tables, reg_table_bytes of device memory)
-size_t reg_table_bytes(const qk_circuit& c, int64_t N);
-int launch_reg_tables(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* tabs, hipStream_t stream);
+//             tabs: the phase tables of its diagonal stages and its matrices, per sample group (launch_reg_side,
+//             reg_side_bytes of device memory)
+size_t reg_side_bytes(const qk_circuit& c, int64_t N);
+int launch_reg_side(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* tabs, hipStream_t stream);
 int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs, const void* tabs, int64_t N, void* psi, void* psi32,
                    hipStream_t stream);
 // qk_sim.hip

@@ -1,6 +1,9 @@
-// Program format of the register-resident simulator (qk_reg.hip): circuits of 10 to 13 qubits that run as ONE pass
-// with every qubit local.  The 2^L amplitudes of a sample live in the registers of one workgroup, 16 per thread,
-// across all stages; LDS only carries them from one register layout to the next.
+// Program format of the register-resident simulator (qk_reg.hip): circuits of 4 to 13 qubits that run as ONE pass
+// with every qubit local.  The 2^L amplitudes of a sample (below 10 qubits: of 2^(L - nq) samples side by side) live in
+// the registers of one workgroup, 16 per thread, across all stages; LDS only carries them from one register layout to
+// the next.  What depends on the sample -- gate angles, phase tables of the diagonal stages, 2x2 matrices -- is
+// computed for the whole batch by pre-pass kernels (one thread per sample) from the records below and fetched by the
+// simulator with LDS-DMA.
 //
 // A layout is a choice of four "register" qubits: a thread's 16 amplitudes differ in exactly those bits, the other
 // L - 4 bits are the thread's index (ascending).  Every non-diagonal gate is applied where its target is a register

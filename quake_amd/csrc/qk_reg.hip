@@ -1,4 +1,4 @@
-// Register-resident statevector simulator for gfx950: circuits of 10 to 13 qubits (format and idea: qk_reg.h).
+// Register-resident statevector simulator for gfx950: circuits of 4 to 13 qubits (format and idea: qk_reg.h).
 //
 // One workgroup of 2^(L-4) threads per sample, 16 amplitudes per thread, held in registers across ALL stages of the
 // circuit.  In a layout four qubits are "register" qubits -- a thread's 16 amplitudes differ in exactly those bits --
@@ -19,6 +19,11 @@
 // cost of that stream (record loads, dispatch, barriers, loop control -- most of what a narrow circuit pays in the
 // wave-resident and LDS kernels) is shared by all samples of the group.  What differs per sample -- angles, matrices,
 // phase tables -- lives in LDS once per sample and is read at a per-lane offset; matrices stay in vector registers.
+//
+// Nothing that depends on the sample is computed here: reg_table_kernel and reg_matrix_kernel (below; one thread per
+// sample and table / matrix, uniform control flow per wave) and angle_table_kernel (qk_sim.hip) prepare the phase
+// tables, the matrices and the (cos, sin) of the angles for the whole batch; the simulator fetches a group's block
+// with LDS-DMA into one of two buffers while the previous group computes, behind one barrier and a counted s_waitcnt.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -648,14 +653,14 @@ __global__ void __launch_bounds__(256) reg_matrix_kernel(const char* blob, const
 }
 
 // bytes of the tables and matrices of a batch of N samples (0: the circuit has neither)
-size_t reg_table_bytes(const qk_circuit& c, int64_t N) {
+size_t reg_side_bytes(const qk_circuit& c, int64_t N) {
     const RegHeader* H = (const RegHeader*)c.reg_blob.data();
     const int sb = H->L - H->nq;
     const int64_t n_group = (N + ((int64_t)1 << sb) - 1) >> sb;
     return (size_t)n_group * ((size_t)((H->n_tab - H->n_itab) * 16 + H->n_mat * 4) << sb) * 16;
 }
 
-int launch_reg_tables(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* tabs, hipStream_t stream) {
+int launch_reg_side(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* tabs, hipStream_t stream) {
     const RegHeader* H = (const RegHeader*)c.reg_blob.data();
     const int n_dtab = H->n_tab - H->n_itab, sb = H->L - H->nq;
     if (N <= 0) return QK_OK;

@@ -1304,11 +1304,11 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
                                    (hipStream_t)stream, (const DevExpr*)((const char*)dt.reg + H->off_expr), H->n_expr, dt.prog, dt.consts,
                                    X_dev + s0 * ldx, ldx, Nc, cs);
             }
-            const size_t tb = reg_table_bytes(c, Nc);
+            const size_t tb = reg_side_bytes(c, Nc);
             rc = QK_OK;
             if (tb > 0) {
                 if (hipMallocAsync(&tabs, tb, (hipStream_t)stream) != hipSuccess) rc = fail(QK_ERR_HIP, "qk_simulate_dev: cannot allocate the phase tables");
-                if (rc == QK_OK) rc = launch_reg_tables(c, dt.reg, cs, Nc, tabs, (hipStream_t)stream);
+                if (rc == QK_OK) rc = launch_reg_side(c, dt.reg, cs, Nc, tabs, (hipStream_t)stream);
             }
             if (rc == QK_OK)
                 rc = launch_reg_sim(c, dt.reg, cs, tabs, Nc, psi32_dev ? nullptr : (void*)((double2*)psi_dev + (s0 << n)),
