@@ -36,9 +36,10 @@ enum RegOpKind : int32_t {
 struct RegOp {        // 32 bytes
     int32_t kind;
     int32_t a, b;
-    int32_t tab;      // INIT / DIAG: first table slot: A, Blo, Bhi (two slots when the thread has nine bits)
-    int32_t t0;       // DIAG: first of the terms evaluated per thread: nTX between two thread bits, then nRT between a
-    int32_t nTX, nRT; //       register bit and a thread bit (RegTerm::rpos = that register position)
+    int32_t tab;      // INIT / DIAG: first table: A, Blo, Bhi (two slots when the thread has nine bits; none when it has at most
+                      // four); DIAG: counted from RegHeader::n_itab
+    int32_t t0;       // DIAG: first of the terms evaluated per thread (RegTerm): nTX between two thread bits, then nRT between a
+    int32_t nTX, nRT; //       register bit and a thread bit (bits 8.. of RegTerm::type = that register position)
     int32_t flags;    // DIAG: bits 0..3 = register positions that have RT terms, bit 8 = the state is still the identity; INIT: bit 0 = every first gate is a Hadamard;
                       // U1: butterfly form (0 real matrix, 1 rx-shaped, 2 general, 3 hadamard)
 };
@@ -83,8 +84,10 @@ struct RegFact {
 };
 
 struct RegHeader {    // at offset 0 of the blob; off_* are byte offsets from its start (16-byte aligned sections)
-    int32_t L, n_seg, n_op, n_tab, n_term, n_expr, n_mat, n_comp, n_fact;
-    int32_t init_h;   // bit 0: every first gate is a Hadamard; bit 1: ONE buffer of stage tables in LDS instead of two
+    int32_t L, n_seg, n_op, n_tab, n_term, n_expr, n_mat;      // n_mat RegMat records, n_fact RegFact records; n_term RegTerm records
+    int32_t n_comp;   // (unused, 0)
+    int32_t n_fact;
+    int32_t init_h;   // bit 0: every first gate is a Hadamard; bit 1: ONE buffer of stage tables and matrices in LDS instead of two
     int32_t off_seg, off_op, off_tab, off_term, off_expr, off_mat, off_comp, off_fact, off_init, bytes;
     int32_t rb, nq;   // register qubits per layout: 4 (16 amplitudes per thread) or 3 (8 per thread, twice the threads);
                       // nq = qubits of the circuit: below L when 2^(L - nq) samples share a workgroup (index bits nq .. L - 1
@@ -93,7 +96,8 @@ struct RegHeader {    // at offset 0 of the blob; off_* are byte offsets from it
     // tables [0, n_itab) belong to the product state (built in the simulator unless init_h), [n_itab, n_tab) to the diagonal
     // stages (RegOp::tab of a DIAG op counts from n_itab); n_tt RegTabTerm records at off_tt
     int32_t n_itab, n_tt, off_tt;
-    int32_t n_expr_k; // the first n_expr_k angle programs are the ones the simulator reads (the rest: table terms only)
+    int32_t n_expr_k; // the first n_expr_k angle programs are the ones the simulator reads itself (per-thread terms); the rest
+                      // feed the pre-pass kernels only (table terms, factors of matrices)
 };
 
 }  // namespace qk
