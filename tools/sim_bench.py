@@ -3,6 +3,10 @@
 import argparse, json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quake_amd import _lib
+if os.environ.get("QK_OLD"):      # same-box A/B against quake_amd/libquake_hip_before.so (a build of another commit, copied there by hand)
+    from pathlib import Path
+    _lib.LIB_PATH = Path(_lib.LIB_PATH).with_name("libquake_hip_before.so")
 from quake_amd import device as qdev, featuremaps as fm
 from quake_amd.circuit import ParameterVector, QuantumCircuit
 
