@@ -623,33 +623,63 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             if (e > b + 1) std::stable_sort(order.begin() + b, order.begin() + e, [&](int x, int y) { return seq[x].nd.q0 < seq[y].nd.q0; });
             b = e > b ? e : b + 1;
         }
-        // register qubits per layout: 3 = 8 amplitudes per thread and twice the threads (twice the waves per CU for the
-        // same LDS: the kernel is bound by latency, not by issue); QK_REG_RB overrides (A/B runs)
-        // (QK_REG_RB=3 selects the 8-amplitude form for A/B runs; it is not the default: at 128 registers the compiler
-        // still spills a few values, and a scratch access would break the kernel's counted memory waits)
-        static const int rb_env = std::getenv("QK_REG_RB") ? std::atoi(std::getenv("QK_REG_RB")) : 0;
-        const int RB = (rb_env == 3 && Lv == n) ? 3 : 4;
-        const int n_samp = 1 << (Lv - n);      // samples per workgroup
+        // Segments: consecutive gates whose non-diagonal qubits fit the RB register qubits of one layout.
         struct SegDraft { std::vector<int> bits, ids; };
-        std::vector<SegDraft> sd(1);
-        for (int id : order) {
-            const Proto& p = seq[id];
-            std::vector<int> need;
-            if (!p.diag) {
-                if (p.nd.kind == ST_U1) need = {p.nd.q0};
-                else if (p.nd.kind == ST_CX) need = {p.nd.q1};
-                else need = {p.nd.q0, p.nd.q1};
+        auto draft = [&](const int RB) {
+            std::vector<SegDraft> sd(1);
+            for (int id : order) {
+                const Proto& p = seq[id];
+                std::vector<int> need;
+                if (!p.diag) {
+                    if (p.nd.kind == ST_U1) need = {p.nd.q0};
+                    else if (p.nd.kind == ST_CX) need = {p.nd.q1};
+                    else need = {p.nd.q0, p.nd.q1};
+                }
+                std::vector<int> b2 = sd.back().bits;
+                for (int q : need)
+                    if (std::find(b2.begin(), b2.end(), q) == b2.end()) b2.push_back(q);
+                if ((int)b2.size() > RB) {
+                    sd.push_back(SegDraft{});
+                    b2 = need;
+                }
+                sd.back().bits = b2;
+                sd.back().ids.push_back(id);
             }
-            std::vector<int> b2 = sd.back().bits;
-            for (int q : need)
-                if (std::find(b2.begin(), b2.end(), q) == b2.end()) b2.push_back(q);
-            if ((int)b2.size() > RB) {
-                sd.push_back(SegDraft{});
-                b2 = need;
+            return sd;
+        };
+        // Register qubits per layout: 4 = 16 amplitudes per thread, 3 = 8 amplitudes and twice the threads.  With 8 a
+        // layer of gates needs more layouts (a transpose through LDS each) and a diagonal stage computes its per-thread
+        // phase for half as many amplitudes; with 16 a CU holds half the waves, and the butterflies with a matrix, the
+        // swaps and the ECRs are chains the other waves have to cover.  Measured (4 GiB of Psi per call, 16 -> 8):
+        //   7 qubits and below, every circuit: 8 wins (6 qubits Z r = 2 3.93 -> 2.62 ms, 5 qubits custom1 r = 2 32.4 -> 19.7);
+        //   GA genomes: 8 wins (12 qubits 1.89 -> 1.76, 11: 2.55 -> 2.13, 10: 2.07 -> 1.52, 9: 3.18 -> 2.63, 8: 2.82 -> 2.31);
+        //   the Z / ZZ maps (diagonal stages and Hadamard layers only): 16 wins (12 qubits ZZ r = 2 1.62 against 1.74);
+        //   custom1 r = 2 (heavy diagonal stages and one layer of rotations): 16 wins where 8 costs a layout more
+        //   (8 qubits 4.19 against 4.97, 10: 2.60 / 2.73, 12: 2.03 / 2.15), 8 where it does not (9 qubits 5.33 -> 3.96).
+        // "busy": gates that are butterflies with a matrix, swaps or ECRs -- not the first gate on a qubit, which goes into
+        // the product state, and not Hadamards, whose layers are sweeps of additions.  QK_REG_RB overrides (A/B runs).
+        static const int rb_env = std::getenv("QK_REG_RB") ? std::atoi(std::getenv("QK_REG_RB")) : 0;
+        int busy = 0, n_diag_terms = 0;
+        {
+            uint32_t seen = 0;
+            for (const Proto& p : seq) {
+                if (p.diag) {
+                    n_diag_terms += (int)p.terms.size();
+                    for (const Item& t : p.terms) seen |= (1u << t.q0) | (t.q1 >= 0 ? 1u << t.q1 : 0u);
+                    continue;
+                }
+                const bool u1 = p.nd.kind == ST_U1;
+                if (u1 && !((seen >> p.nd.q0) & 1u)) { seen |= 1u << p.nd.q0; continue; }
+                if (!(u1 && p.nd.gate == QK_H)) ++busy;
+                seen |= (1u << p.nd.q0) | (p.nd.q1 >= 0 ? 1u << p.nd.q1 : 0u);
             }
-            sd.back().bits = b2;
-            sd.back().ids.push_back(id);
         }
+        int RB = 4;
+        if (rb_env == 3 || rb_env == 4) RB = rb_env;
+        else if (n <= 7) RB = 3;
+        else if (2 * busy >= n) RB = (n_diag_terms >= 2 * n && draft(3).size() > draft(4).size()) ? 4 : 3;
+        const int n_samp = 1 << (Lv - n);      // samples per workgroup
+        std::vector<SegDraft> sd = draft(RB);
         for (SegDraft& g : sd) {      // fill the group with the highest qubits it does not hold yet
             for (int q = n - 1; q >= 0 && (int)g.bits.size() < RB; --q)
                 if (std::find(g.bits.begin(), g.bits.end(), q) == g.bits.end()) g.bits.push_back(q);
@@ -912,7 +942,10 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         const size_t nd = (n_slot / 64 + waves - 1) / waves + (t_slot + waves - 1) / waves;    // fetch instructions per wave and sample group
         if (std::getenv("QK_REG_DEBUG")) std::fprintf(stderr, "[reg plan] Lv=%d fits=%d nd=%zu lds=%zu limit=%zu tabs=%zu terms=%zu mats=%zu\n", Lv, (int)fits, nd, lds, lds_limit, tabs.size(), rterms.size(), rmats.size());
         if (!(fits && nd <= 64 && lds <= lds_limit)) return false;
-        if (dry_lds) { *dry_lds = all_h ? lds : (lds | ((size_t)1 << 40)); return true; }      // (bit 40: product-state tables are built in the kernel)
+        if (dry_lds) {      // (bit 40: product-state tables are built in the kernel; bit 41: 8 amplitudes per thread)
+            *dry_lds = lds | (all_h ? (size_t)0 : (size_t)1 << 40) | (RB == 3 ? (size_t)1 << 41 : (size_t)0);
+            return true;
+        }
         {
             auto pad16 = [](size_t b) { return (b + 15) / 16 * 16; };
             RegHeader H{};
@@ -961,7 +994,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         static const int lv_wide = std::getenv("QK_REG_LV") ? std::atoi(std::getenv("QK_REG_LV")) : 0;
         if (!(lv_wide > n && lv_wide <= kRegPackMaxWidth && plan_reg(lv_wide, (size_t)160 * 1024))) plan_reg(n, (size_t)160 * 1024);
     } else if (n >= kRegPackMinQubits && n < kRegMinQubits && c.passes.size() == 1 && c.passes[0].L == n) {
-        // The width that keeps the most waves resident on a CU (LDS per workgroup against 2 waves per SIMD at 247 VGPRs);
+        // The width that keeps the most waves resident on a CU (LDS per workgroup against 3 waves per SIMD at 147 VGPRs);
         // among equals the narrowest workgroup, whose barriers cost least (9 qubits, GA genome: 3.9 ms at L = 10 with five
         // waves per CU, 5.1 at L = 11 and 4.3 at L = 12 with four; 8 qubits ZZ r = 2: 2.5 / 2.5 / 2.8 ms with 6 / 6 / 4).
         // QK_REG_LV forces one (A/B runs).
@@ -975,7 +1008,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             // a first layer that is not all Hadamards (GA genomes) has its product-state tables built inside the kernel, a
             // wave per sample and a barrier behind it: single-wave workgroups (L = 10) keep that wave-local
             if (((lds >> 40) & 1) && n >= 7) { best = Lv; break; }      // (6 qubits and below: 16+ samples per wave either way, the count decides)
-            const int waves = std::min(8, (int)((size_t)160 * 1024 / (lds & (((size_t)1 << 40) - 1))) * ((1 << (Lv - 4)) / 64));
+            const int rb = ((lds >> 41) & 1) ? 3 : 4;
+            const int waves = std::min(rb == 3 ? 16 : 12, (int)((size_t)160 * 1024 / (lds & (((size_t)1 << 40) - 1))) * ((1 << (Lv - rb)) / 64));
             if (waves > best_waves) { best_waves = waves; best = Lv; }
         }
         if (!done && best) plan_reg(best, (size_t)160 * 1024);

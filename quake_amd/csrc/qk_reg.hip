@@ -30,6 +30,9 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "qk_common.h"
 #include "qk_reg.h"
@@ -103,6 +106,21 @@ __device__ __forceinline__ v2d term_factor(const TermL& t, uint32_t w) {
 __device__ __forceinline__ uint32_t swz(uint32_t i) { return i ^ ((i >> 4) & 15u) ^ ((i >> 8) & 15u) ^ ((i >> 12) & 15u); }
 
 template <int V> struct IC { static constexpr int value = V; };
+
+// The thread's amplitudes as 2 NA separate doubles, not NA two-element vectors: a vector-typed value that is live across
+// the op dispatch becomes a 128-bit register tuple whose halves the allocator will not update in place, and every join
+// behind a butterfly then copies all of them (877 v_mov_b64 of 5618 instructions with v2d v[NA]).
+template <int NA> struct Amps {
+    double re[NA], im[NA];
+    struct Ref {
+        double& x;
+        double& y;
+        __device__ __forceinline__ operator v2d() const { return (v2d){x, y}; }
+        __device__ __forceinline__ Ref& operator=(v2d a) { x = a.x; y = a.y; return *this; }
+        __device__ __forceinline__ Ref& operator=(const Ref& r) { const double rx = r.x, ry = r.y; x = rx; y = ry; return *this; }
+    };
+    __device__ __forceinline__ Ref operator[](int k) { return Ref{re[k], im[k]}; }
+};
 template <class F>
 __device__ __forceinline__ void with_pos(int p, F&& f) {      // p is wave-uniform: ONE scalar dispatch, straight-line code behind it
     if (p == 0) f(IC<0>());
@@ -111,20 +129,141 @@ __device__ __forceinline__ void with_pos(int p, F&& f) {      // p is wave-unifo
     else f(IC<3>());
 }
 
+// In-place arithmetic on the amplitude registers.  Every result is written onto one of its own inputs (a tied asm
+// operand), so a value that is live across the op dispatch keeps its register: written as plain expressions, the
+// butterflies of an arm go to a second set of 64 registers and every join copies it back (32 v_mov_b64 per
+// register position and op -- a third of a single-qubit gate's instructions).  `dep` operands are not read: they
+// order an instruction behind the last reader of the value it overwrites.  VM: multiplier in a vector register
+// (packed samples: every lane has its own matrix), else in scalar registers.
+template <bool VM> __device__ __forceinline__ void ip_mul(double& p, double m, double dep) {       // p = m p
+    if constexpr (VM) asm("v_mul_f64 %0, %1, %0" : "+v"(p) : "v"(m), "v"(dep));
+    else asm("v_mul_f64 %0, %1, %0" : "+v"(p) : "s"(m), "v"(dep));
+}
+template <bool VM, bool NEG> __device__ __forceinline__ void ip_fma_acc(double& p, double m, double q) {      // p = (+-m) q + p
+    if constexpr (VM) {
+        if constexpr (NEG) asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(p) : "v"(m), "v"(q));
+        else asm("v_fma_f64 %0, %1, %2, %0" : "+v"(p) : "v"(m), "v"(q));
+    } else {
+        if constexpr (NEG) asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(p) : "s"(m), "v"(q));
+        else asm("v_fma_f64 %0, %1, %2, %0" : "+v"(p) : "s"(m), "v"(q));
+    }
+}
+template <bool VM> __device__ __forceinline__ void ip_fma_self(double& q, double m, double t, double d0, double d1, double d2) {      // q = m q + t
+    if constexpr (VM) asm("v_fma_f64 %0, %1, %0, %2" : "+v"(q) : "v"(m), "v"(t), "v"(d0), "v"(d1), "v"(d2));
+    else asm("v_fma_f64 %0, %1, %0, %2" : "+v"(q) : "s"(m), "v"(t), "v"(d0), "v"(d1), "v"(d2));
+}
+// v <- v * ph (complex), in place
+__device__ __forceinline__ void ip_cmul(double& x, double& y, v2d ph) {
+    const double t = x * ph.y;
+    ip_mul<true>(x, ph.x, t);
+    ip_fma_acc<true, true>(x, ph.y, y);
+    ip_fma_self<true>(y, ph.x, t, x, x, x);
+}
+
+// The butterflies of one register position go stage by stage over all eight pairs, so that an instruction and the one
+// that needs its result are sixteen instructions apart (a 64-bit operation occupies the SIMD for four cycles and its
+// result takes longer than that: with one or two waves on a SIMD a dependent pair back to back stalls).
+// pair j of position P: registers lo(j) and lo(j) | (1 << P)
+template <int P> __device__ __forceinline__ constexpr int pair_lo(int j) { return ((j >> P) << (P + 1)) | (j & ((1 << P) - 1)); }
+
+// (a0, a1) <- (a0 + a1, a0 - a1): the difference as (a0 + a1) - 2 a1, onto a1
+template <int P, int NA> __device__ __forceinline__ void hadamard_pos(Amps<NA>& v) {
+    if constexpr ((1 << P) < NA) {
+#pragma unroll
+        for (int j = 0; j < NA / 2; ++j) {
+            const int k = pair_lo<P>(j), h = k | (1 << P);
+            asm("v_add_f64 %0, %0, %1" : "+v"(v.re[k]) : "v"(v.re[h]));
+            asm("v_add_f64 %0, %0, %1" : "+v"(v.im[k]) : "v"(v.im[h]));
+        }
+#pragma unroll
+        for (int j = 0; j < NA / 2; ++j) {
+            const int k = pair_lo<P>(j), h = k | (1 << P);
+            asm("v_fma_f64 %0, -2.0, %0, %1" : "+v"(v.re[h]) : "v"(v.re[k]));
+            asm("v_fma_f64 %0, -2.0, %0, %1" : "+v"(v.im[h]) : "v"(v.im[k]));
+        }
+    }
+}
+
+// NA real systems [p; q] <- [A, +-B; +-C, D] [p; q]: system 2 j is (re[lo], CROSS ? im[hi] : re[hi]) with signs (NB0, NC0),
+// system 2 j + 1 is (im[lo], CROSS ? re[hi] : im[hi]) with (NB1, NC1); four instructions and one temporary each
+template <int P, int NA, bool VM, bool CROSS, bool NB0, bool NC0, bool NB1, bool NC1>
+__device__ __forceinline__ void sys2_pos(Amps<NA>& v, double A, double B, double C, double D) {
+    double t[NA];
+#pragma unroll
+    for (int j = 0; j < NA / 2; ++j) {
+        const int k = pair_lo<P>(j);
+        t[2 * j] = NC0 ? -(C * v.re[k]) : C * v.re[k];
+        t[2 * j + 1] = NC1 ? -(C * v.im[k]) : C * v.im[k];
+    }
+#pragma unroll
+    for (int j = 0; j < NA / 2; ++j) {
+        const int k = pair_lo<P>(j);
+        ip_mul<VM>(v.re[k], A, t[2 * j]);
+        ip_mul<VM>(v.im[k], A, t[2 * j + 1]);
+    }
+#pragma unroll
+    for (int j = 0; j < NA / 2; ++j) {
+        const int k = pair_lo<P>(j), h = k | (1 << P);
+        ip_fma_acc<VM, NB0>(v.re[k], B, CROSS ? v.im[h] : v.re[h]);
+        ip_fma_acc<VM, NB1>(v.im[k], B, CROSS ? v.re[h] : v.im[h]);
+    }
+#pragma unroll
+    for (int j = 0; j < NA / 2; ++j) {
+        const int k = pair_lo<P>(j), h = k | (1 << P);
+        ip_fma_self<VM>(CROSS ? v.im[h] : v.re[h], D, t[2 * j], v.re[k], v.re[k], v.re[k]);
+        ip_fma_self<VM>(CROSS ? v.re[h] : v.im[h], D, t[2 * j + 1], v.im[k], v.im[k], v.im[k]);
+    }
+}
+
+// a general complex matrix: a0 <- m0 a0 + m1 a1, a1 <- m2 a0 + m3 a1; sixteen instructions and four temporaries a pair,
+// four pairs at a time
+template <int P, int NA, bool VM>
+__device__ __forceinline__ void gen2_pos(Amps<NA>& v, double m0x, double m0y, double m1x, double m1y, double m2x, double m2y, double m3x, double m3y) {
+    constexpr int CH = NA / 2 < 4 ? NA / 2 : 4;
+#pragma unroll
+    for (int j0 = 0; j0 < NA / 2; j0 += CH) {
+        double tx[CH], ty[CH], ux[CH], uy[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {      // what each amplitude adds to the other one, from the old values
+            const int k = pair_lo<P>(j0 + j), h = k | (1 << P);
+            tx[j] = fma(m2x, v.re[k], -(m2y * v.im[k])); ty[j] = fma(m2x, v.im[k], m2y * v.re[k]);      // m2 a0 -> a1
+            ux[j] = fma(m1x, v.re[h], -(m1y * v.im[h])); uy[j] = fma(m1x, v.im[h], m1y * v.re[h]);      // m1 a1 -> a0
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int k = pair_lo<P>(j0 + j), h = k | (1 << P);
+            ip_fma_acc<VM, false>(uy[j], m0y, v.re[k]);
+            ip_fma_acc<VM, false>(ty[j], m3y, v.re[h]);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {      // (behind every reader of the old real parts)
+            const int k = pair_lo<P>(j0 + j), h = k | (1 << P);
+            ip_fma_self<VM>(v.re[k], m0x, ux[j], tx[j], ty[j], uy[j]);
+            ip_fma_self<VM>(v.re[h], m3x, tx[j], ux[j], uy[j], ty[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int k = pair_lo<P>(j0 + j), h = k | (1 << P);
+            ip_fma_acc<VM, true>(v.re[k], m0y, v.im[k]);
+            ip_fma_acc<VM, true>(v.re[h], m3y, v.im[h]);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {      // (behind every reader of the old imaginary parts)
+            const int k = pair_lo<P>(j0 + j), h = k | (1 << P);
+            ip_fma_self<VM>(v.im[k], m0x, uy[j], v.re[k], v.re[h], v.re[k]);
+            ip_fma_self<VM>(v.im[h], m3x, ty[j], v.re[h], v.re[k], v.re[h]);
+        }
+    }
+}
+
 // a 2x2 matrix on register position P: eight butterflies between registers k and k | (1 << P).  form: 0 real matrix
 // (x, ry), 1 real diagonal + imaginary off-diagonal (rx), 2 general (sx, composites), 3 hadamard (adds only; its
 // 1 / sqrt 2 goes to the running scale).  e0 .. e3: the matrix as it came out of LDS (not read for a hadamard).
 template <int P, int NA, bool PACK>
-__device__ __forceinline__ void u1_reg(v2d (&v)[NA], v2d e0, v2d e1, v2d e2, v2d e3, int form, double& scale) {
+__device__ __forceinline__ void u1_reg(Amps<NA>& v, v2d e0, v2d e1, v2d e2, v2d e3, int form, double& scale) {
     if constexpr ((1 << P) >= NA) return;
     if (form == 3) {
-#pragma unroll
-        for (int k = 0; k < NA; ++k)
-            if (!((k >> P) & 1)) {
-                const v2d a0 = v[k], a1 = v[k | (1 << P)];
-                v[k] = a0 + a1;
-                v[k | (1 << P)] = a0 - a1;
-            }
+        hadamard_pos<P, NA>(v);
         scale *= 0.70710678118654752440;
         return;
     }
@@ -133,36 +272,17 @@ __device__ __forceinline__ void u1_reg(v2d (&v)[NA], v2d e0, v2d e1, v2d e2, v2d
     const double m0x = un(e0.x), m0y = un(e0.y), m1x = un(e1.x), m1y = un(e1.y);
     const double m2x = un(e2.x), m2y = un(e2.y), m3x = un(e3.x), m3y = un(e3.y);
     if (form == 0) {
-#pragma unroll
-        for (int k = 0; k < NA; ++k)
-            if (!((k >> P) & 1)) {
-                const v2d a0 = v[k], a1 = v[k | (1 << P)];
-                v[k] = (v2d){fma(m1x, a1.x, m0x * a0.x), fma(m1x, a1.y, m0x * a0.y)};
-                v[k | (1 << P)] = (v2d){fma(m3x, a1.x, m2x * a0.x), fma(m3x, a1.y, m2x * a0.y)};
-            }
+        sys2_pos<P, NA, PACK, false, false, false, false, false>(v, m0x, m1x, m2x, m3x);
     } else if (form == 1) {
-#pragma unroll
-        for (int k = 0; k < NA; ++k)
-            if (!((k >> P) & 1)) {
-                const v2d a0 = v[k], a1 = v[k | (1 << P)];
-                v[k] = (v2d){fma(-m1y, a1.y, m0x * a0.x), fma(m1y, a1.x, m0x * a0.y)};
-                v[k | (1 << P)] = (v2d){fma(-m2y, a0.y, m3x * a1.x), fma(m2y, a0.x, m3x * a1.y)};
-            }
+        // a0.x' = m0x a0.x - m1y a1.y, a1.y' = m2y a0.x + m3x a1.y;  a0.y' = m0x a0.y + m1y a1.x, a1.x' = -m2y a0.y + m3x a1.x
+        sys2_pos<P, NA, PACK, true, true, false, false, true>(v, m0x, m1y, m2y, m3x);
     } else {
-#pragma unroll
-        for (int k = 0; k < NA; ++k)
-            if (!((k >> P) & 1)) {
-                const v2d a0 = v[k], a1 = v[k | (1 << P)];
-                v[k] = (v2d){fma(m1x, a1.x, fma(-m1y, a1.y, fma(m0x, a0.x, -(m0y * a0.y)))),
-                             fma(m1x, a1.y, fma(m1y, a1.x, fma(m0x, a0.y, m0y * a0.x)))};
-                v[k | (1 << P)] = (v2d){fma(m3x, a1.x, fma(-m3y, a1.y, fma(m2x, a0.x, -(m2y * a0.y)))),
-                                        fma(m3x, a1.y, fma(m3y, a1.x, fma(m2x, a0.y, m2y * a0.x)))};
-            }
+        gen2_pos<P, NA, PACK>(v, m0x, m0y, m1x, m1y, m2x, m2y, m3x, m3y);
     }
 }
 
 template <int C, int T, int NA>
-__device__ __forceinline__ void cx_reg(v2d (&v)[NA]) {
+__device__ __forceinline__ void cx_reg(Amps<NA>& v) {
     if constexpr (C != T && (1 << C) < NA && (1 << T) < NA) {
 #pragma unroll
         for (int k = 0; k < NA; ++k)
@@ -175,7 +295,7 @@ __device__ __forceinline__ void cx_reg(v2d (&v)[NA]) {
 }
 
 template <int T, int NA>
-__device__ __forceinline__ void cx_thread(v2d (&v)[NA], bool on) {
+__device__ __forceinline__ void cx_thread(Amps<NA>& v, bool on) {
     if constexpr ((1 << T) >= NA) return;
 #pragma unroll
     for (int k = 0; k < NA; ++k)
@@ -188,7 +308,7 @@ __device__ __forceinline__ void cx_thread(v2d (&v)[NA], bool on) {
 
 // ecr(q0, q1) on register positions P0, P1 (matrix index 2 bit(q1) + bit(q0)); its 1 / sqrt 2 goes to the scale
 template <int P0, int P1, int NA>
-__device__ __forceinline__ void ecr_reg(v2d (&v)[NA]) {
+__device__ __forceinline__ void ecr_reg(Amps<NA>& v) {
     if constexpr (P0 != P1 && (1 << P0) < NA && (1 << P1) < NA) {
 #pragma unroll
         for (int k = 0; k < NA; ++k)
@@ -207,8 +327,11 @@ __device__ __forceinline__ void ecr_reg(v2d (&v)[NA]) {
 // TBN = log2(threads), RB = register qubits per layout (NA = 2^RB amplitudes per thread), L = TBN + RB.
 // RB = 4: two waves per SIMD (256 VGPRs); RB = 3: four (128 VGPRs) -- LDS holds the same number of samples either way.
 // PACK: 2^(L - nq) samples per workgroup (see the top of the file); nq = L otherwise.
+// Waves per SIMD, lower and upper bound alike: LDS, not registers, decides how many workgroups a CU holds (two states of 12
+// qubits, seven of 10), so the scheduler is told not to trade instruction-level parallelism for an occupancy the kernel
+// cannot have.
 template <int TBN, int RB, bool PACK>
-__global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegArgs a) {
+__global__ void __launch_bounds__(1 << TBN) __attribute__((amdgpu_waves_per_eu(RB == 3 ? 4 : 2, RB == 3 ? 4 : 2))) reg_sim_kernel(RegArgs a) {
     extern __shared__ double2 lds[];
     constexpr int L = TBN + RB, T = 1 << TBN, NA = 1 << RB;
     const CWords hw = cwords(a.blob);
@@ -351,7 +474,7 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
         }
         QK_RMARK(11);
 
-        v2d v[NA];
+        Amps<NA> v;
         double scale = 1.0;
         // this lane's sample of the group and where its terms, matrices and tables are
         const uint32_t sid = PACK ? (uint32_t)tid >> (nq - RB) : 0u;
@@ -399,15 +522,10 @@ __global__ void __launch_bounds__(1 << TBN, RB == 3 ? 4 : 2) reg_sim_kernel(RegA
                 }
                 if (kind == RG_U1) {
                     if (oa == NA - 1 && o_flags == (RB == 4 ? 0xff : 0x3f)) {      // a Hadamard on every register qubit: no matrices
-#pragma unroll
-                        for (int p = 0; p < RB; ++p)
-#pragma unroll
-                            for (int k = 0; k < NA; ++k)
-                                if (!((k >> p) & 1)) {
-                                    const v2d a0 = v[k], a1 = v[k | (1 << p)];
-                                    v[k] = a0 + a1;
-                                    v[k | (1 << p)] = a0 - a1;
-                                }
+hadamard_pos<0, NA>(v);
+                        hadamard_pos<1, NA>(v);
+                        hadamard_pos<2, NA>(v);
+                        hadamard_pos<3, NA>(v);
                         scale *= RB == 4 ? 0.25 : 0.35355339059327376220;
                     } else {
                         // the matrix of the next position is read while the butterflies of the current one run
@@ -681,14 +799,16 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
     const RegHeader* H = (const RegHeader*)c.reg_blob.data();
     const int L = H->L, RB = H->rb;      // L > n_qubits: 2^(L - n_qubits) samples per workgroup
     const bool pack = H->nq < L;
-    const void* fns[3][4] = {{(const void*)reg_sim_kernel<7, 3, false>, (const void*)reg_sim_kernel<8, 3, false>, (const void*)reg_sim_kernel<9, 3, false>, (const void*)reg_sim_kernel<10, 3, false>},
+    // [8 amplitudes per thread | 16 | 16, packed samples | 8, packed samples][L - 10]
+    const void* fns[4][4] = {{(const void*)reg_sim_kernel<7, 3, false>, (const void*)reg_sim_kernel<8, 3, false>, (const void*)reg_sim_kernel<9, 3, false>, (const void*)reg_sim_kernel<10, 3, false>},
                              {(const void*)reg_sim_kernel<6, 4, false>, (const void*)reg_sim_kernel<7, 4, false>, (const void*)reg_sim_kernel<8, 4, false>, (const void*)reg_sim_kernel<9, 4, false>},
-                             {(const void*)reg_sim_kernel<6, 4, true>, (const void*)reg_sim_kernel<7, 4, true>, (const void*)reg_sim_kernel<8, 4, true>, nullptr}};
-    if (H->nq != c.n_qubits || L < kRegMinQubits || L > kRegMaxQubits || (pack && (RB != 4 || L > kRegPackMaxWidth)))
+                             {(const void*)reg_sim_kernel<6, 4, true>, (const void*)reg_sim_kernel<7, 4, true>, (const void*)reg_sim_kernel<8, 4, true>, nullptr},
+                             {(const void*)reg_sim_kernel<7, 3, true>, (const void*)reg_sim_kernel<8, 3, true>, (const void*)reg_sim_kernel<9, 3, true>, nullptr}};
+    if (H->nq != c.n_qubits || L < kRegMinQubits || L > kRegMaxQubits || (RB != 3 && RB != 4) || (pack && L > kRegPackMaxWidth))
         return fail(QK_ERR_INVALID, "register-resident simulator: malformed plan");
     static DeviceOnce attr_set;
     if (attr_set.pending()) {
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 4; ++r)
             for (int k = 0; k < 4; ++k)
                 if (fns[r][k]) QK_HIP(hipFuncSetAttribute(fns[r][k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
@@ -709,14 +829,34 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
 #endif
     const size_t lds = c.reg_lds_bytes;
     const int threads = 1 << (L - RB);
-    // resident workgroups per CU: LDS, and registers (RB = 4: 256 VGPRs, 8 waves per CU; RB = 3: 128 VGPRs, 16 waves)
-    int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)std::max(1, (RB == 3 ? 1024 : 512) / threads));
+    // Resident workgroups per CU, as the runtime counts them for this kernel's registers and this plan's LDS: the grid is
+    // exactly what the chip holds at once, every workgroup walking its share of the sample groups.  (Asked, not assumed:
+    // a grid sized for fewer workgroups than a CU takes lets the dispatcher fill some CUs and leave others short.)
+    const void* fn = fns[pack ? (RB == 3 ? 3 : 2) : (RB == 3 ? 0 : 1)][L - 10];
+    int per_cu = 0;
+    {
+        static std::mutex mu;
+        static std::map<std::tuple<int, const void*, size_t>, int> cache;
+        int dev = 0;
+        QK_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        const auto key = std::make_tuple(dev, fn, lds);
+        const auto it = cache.find(key);
+        if (it != cache.end()) per_cu = it->second;
+        else {
+            QK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds));
+            cache[key] = per_cu;
+        }
+    }
+    if (const char* e = std::getenv("QK_REG_PER_CU")) per_cu = std::atoi(e);      // A/B runs
     per_cu = std::max(1, per_cu);
+    static const bool debug = std::getenv("QK_REG_DEBUG") != nullptr;
+    if (debug) std::fprintf(stderr, "[reg] L=%d nq=%d RB=%d threads=%d lds=%zu workgroups per CU=%d\n", L, H->nq, RB, threads, lds, per_cu);
     const int64_t n_group = (N + ((int64_t)1 << (L - H->nq)) - 1) >> (L - H->nq);
     const int64_t nblocks = std::min<int64_t>(n_group, (int64_t)256 * per_cu);
     const dim3 grid((unsigned)nblocks), block(threads);
     void* args[] = {&a};
-    QK_HIP(hipLaunchKernel(fns[pack ? 2 : (RB == 3 ? 0 : 1)][L - 10], grid, block, args, lds, stream));
+    QK_HIP(hipLaunchKernel(fn, grid, block, args, lds, stream));
     QK_HIP(hipGetLastError());
 #ifdef QK_REG_TRACE
     {

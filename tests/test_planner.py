@@ -99,7 +99,7 @@ def test_wave_program_is_refused_when_its_tables_exceed_the_dynamic_lds_limit():
 
 def test_packed_register_plans_below_ten_qubits():
     """4 to 9 qubits: the register-resident plan packs 2^(L - n) samples into a workgroup (qk_reg.h); deep circuits on
-    4-6 qubits, whose per-sample tables and matrices would not fit next to that many samples, have no such plan and
+    4-5 qubits, whose per-sample tables and matrices would not fit next to that many samples, have no such plan and
     stay on the wave-resident kernel; 10 qubits and more: one sample per workgroup."""
     from tests.test_gpu_parity import _gate_soup
 
@@ -110,10 +110,12 @@ def test_packed_register_plans_below_ten_qubits():
 
     for n in (4, 5, 6, 7, 8, 9):
         p = plan_of(zz(n, 1))
-        assert p is not None and p[3] * (1 << n) == 16 * p[4], (n, p)      # samples x amplitudes = 16 per thread
-        assert p[3] >= 2 and p[4] in (64, 128, 256)
+        per_thread = 8 if n <= 7 else 16      # 7 qubits and below: 8 amplitudes per thread on twice the threads
+        assert p is not None and p[3] * (1 << n) == per_thread * p[4], (n, p)      # samples x amplitudes
+        assert p[3] >= 2 and p[4] in (64, 128, 256, 512)
     assert plan_of(zz(8, 2))[0] == 2 and plan_of(zz(9, 2))[0] == 3           # segments of four register qubits
     assert plan_of(zz(12, 2))[3:] == (1, 256) and plan_of(zz(10, 2))[3:] == (1, 64)
-    assert plan_of(_gate_soup(4, 30, 36)) is None and plan_of(_gate_soup(6, 32, 54)) is None
+    assert plan_of(_gate_soup(4, 30, 36)) is None      # 64 samples' tables and matrices next to each other: no room
+    assert plan_of(_gate_soup(6, 32, 54))[3:] == (16, 128)      # 8 amplitudes per thread: 16 samples, not 64, share a workgroup
     assert plan_of(_gate_soup(8, 34, 72)) is not None and plan_of(_gate_soup(13, 22, 117)) is not None
     assert plan_of(zz(3, 1)) is None and plan_of(zz(14, 2)) is None          # below 4 qubits / two passes

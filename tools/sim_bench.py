@@ -4,9 +4,9 @@ import argparse, json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quake_amd import _lib
-if os.environ.get("QK_OLD"):      # same-box A/B against quake_amd/libquake_hip_before.so (a build of another commit, copied there by hand)
+if os.environ.get("QK_OLD"):      # same-box A/B against another build of the library, copied next to it by hand: QK_OLD=1 -> libquake_hip_before.so, QK_OLD=name -> libquake_hip_name.so
     from pathlib import Path
-    _lib.LIB_PATH = Path(_lib.LIB_PATH).with_name("libquake_hip_before.so")
+    _lib.LIB_PATH = Path(_lib.LIB_PATH).with_name("libquake_hip_%s.so" % ("before" if os.environ["QK_OLD"] == "1" else os.environ["QK_OLD"]))
 from quake_amd import device as qdev, featuremaps as fm
 from quake_amd.circuit import ParameterVector, QuantumCircuit
 
@@ -24,7 +24,7 @@ def circuits(n):
     extra = {}
     if n >= 9:
         extra = {"ph_low3x4": ph([0, 1, 2]), "ph_mid3x4": ph([3, 4, 5]), "ph_high3x4": ph([n - 4, n - 5, n - 6])}
-    if n <= 12:      # a GA chromosome (v3 decoder, every gate of the alphabet): the config-3 circuit shape
+    if n <= 13:      # a GA chromosome (v3 decoder, every gate of the alphabet): the config-3 circuit shape
         from quake_amd import genetic
         gd = {"single_non_parametric": ["Id", "H", "X", "SX"], "single_parametric": ["RX", "RY", "RZ"],
               "two_non_parametric": ["CX"], "two_parametric": []}
@@ -33,7 +33,8 @@ def circuits(n):
         if g.num_parameters == n:
             extra["genome_g8"] = g
     return {"h_only": h, "z_r1": hp, "z_r2": fm.z_featuremap(x, n, 2), "zz_r1": fm.zz_featuremap(x, n, 1), "zz_r2": fm.zz_featuremap(x, n, 2),
-            "custom1_r1": fm.custom1_featuremap(x, n, 1), "custom2_r1": fm.custom2_featuremap(x, n, 1), **extra}
+            "custom1_r1": fm.custom1_featuremap(x, n, 1), "custom2_r1": fm.custom2_featuremap(x, n, 1),
+            "custom1_r2": fm.custom1_featuremap(x, n, 2), "custom2_r2": fm.custom2_featuremap(x, n, 2), **extra}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--qubits", type=int, nargs="+", default=[16, 13, 12, 10, 8])
