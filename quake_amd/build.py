@@ -40,11 +40,12 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> 
     # defeat that (common-code sinking merges the per-qubit arms into pointer selects, the AMDGPU alloca-to-vector
     # pass turns the amplitude array into one 32-register tuple): both off for that file
     keep_in_regs = ["-mllvm", "-simplifycfg-sink-common=false", "-mllvm", "-disable-promote-alloca-to-vector"]
-    # qk_reg.hip, in addition: the AMDGPU back end structurizes wave-uniform control flow as well (its StructurizeCFG runs
+    # In addition: the AMDGPU back end structurizes wave-uniform control flow as well (its StructurizeCFG runs
     # with SkipUniformRegions off), which turns the op dispatch's if / else-if chain into a chain of flow blocks that
     # carry BOTH the old and the new amplitudes -- twice the registers (247 instead of 128) and a copy of all of them
     # at every join.  Uniform regions are left as scalar branches instead.
-    per_file = {"qk_wave.hip": keep_in_regs, "qk_reg.hip": keep_in_regs + ["-mllvm", "-structurizecfg-skip-uniform-regions"]}
+    uniform_flow = keep_in_regs + ["-mllvm", "-structurizecfg-skip-uniform-regions"]
+    per_file = {"qk_wave.hip": uniform_flow, "qk_reg.hip": uniform_flow}
     procs = []
     for s in SOURCES:
         obj = objdir / (s.rsplit(".", 1)[0] + ".o")
