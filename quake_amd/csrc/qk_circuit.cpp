@@ -608,6 +608,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     // layout and no gate touches them, so one instruction stream (segments, ops, transposes) serves all those samples
     // and only the angles, matrices and phase tables exist once per sample.
     c.reg_blob.clear();
+    bool q_tables = true;      // register-thread terms of diagonal stages as ratio tables (below)
     auto plan_reg = [&](const int Lv, const size_t lds_limit, size_t* dry_lds = nullptr) -> bool {      // dry_lds: only report the LDS a workgroup would need
         // Single-qubit gates on distinct qubits with nothing between them commute: inside such a run the gates are
         // taken in ascending qubit order, so that a layer of gates fills whole groups of four neighbouring qubits and
@@ -770,17 +771,20 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             // three tables (four when the thread has nine bits): register bits, low thread bits, high thread bits
             // three tables: register bits, low thread bits, high thread bits -- the last one in 2^(extra) slots of 16
             // entries when the thread has more than eight bits (slot = value of the extra bits, ascending)
-            auto tables = [&](int tA, int nA, int tL, int nL, int tH, int nH) {
-                const int first = (int)tabs.size();
-                table(g.bits, 0, 0u, tA, nA);
+            auto thread_tables = [&](int tL, int nL, int tH, int nH) {
                 table(lo, 0, 0u, tL, nL);
                 const int extra = std::max(0, (int)hi.size() - 4);
-                for (int x = 0; x < (1 << extra) && !hi.empty(); ++x) {     // (no high thread qubits: no third table)
+                for (int x = 0; x < (1 << extra) && !hi.empty(); ++x) {     // (no high thread qubits: no such table)
                     uint32_t fixed = 0;
                     for (int b = 0; b < extra; ++b)
                         if ((x >> b) & 1) fixed |= 1u << hi[4 + b];
                     table(hi, 0, fixed, tH, nH);
                 }
+            };
+            auto tables = [&](int tA, int nA, int tL, int nL, int tH, int nH) {
+                const int first = (int)tabs.size();
+                table(g.bits, 0, 0u, tA, nA);
+                thread_tables(tL, nL, tH, nH);
                 return first;
             };
             uint32_t extra_mask = 0;
@@ -811,18 +815,57 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                         else k = 3;
                         cls[k].push_back(t);
                     }
+                    // A term between a register qubit and a thread qubit (class RT), as tables: what the term is while the
+                    // register bit is 0 depends on the thread bit alone and joins that bit's thread table; what flipping
+                    // the register bit multiplies the phase by -- exp(+-i theta) by the thread bit for a ZZ term, -1 where
+                    // the thread bit is set for a CZ -- goes into a pair of "ratio" tables per register position (low and
+                    // high thread bits), which the kernel multiplies into its Gray-code walk.  Evaluated per thread instead
+                    // (q_tables off), every such term costs each thread two factors and three complex products.
+                    constexpr int kRatio = 0x100;
+                    std::vector<Item> ratio[4][2];      // [register position][low / high thread bits]
+                    // Worth it from three terms per register position (a map with full entanglement: 8 per position at 12
+                    // qubits, ZZ r = 2 4.78 -> 2.27 ms per 4 GiB); the linear maps have one or two such terms per stage,
+                    // which cost less than the tables' place in LDS (10 qubits ZZ r = 2: 1.94 ms without, 2.12 with).
+                    uint32_t rt_pos = 0;
+                    for (const Item& t : cls[4]) rt_pos |= 1u << rpos(in(g.bits, t.q0) ? t.q0 : t.q1);
+                    if (q_tables && (int)cls[4].size() >= 3 * __builtin_popcount(rt_pos) && !cls[4].empty()) {
+                        for (const Item& t : cls[4]) {
+                            const bool reg0 = in(g.bits, t.q0);
+                            const int rq = reg0 ? t.q0 : t.q1, tq = reg0 ? t.q1 : t.q0;
+                            const int half = in(lo, tq) ? 0 : 1;
+                            Item r = t;
+                            r.q0 = tq; r.q1 = -1;
+                            ratio[rpos(rq)][half].push_back(r);
+                            op.flags |= (1 << rpos(rq)) | 512;
+                            if (t.kind == TM_ZZP) {      // register bit 0: exp(i theta) where the thread bit is set -- a phase gate on it
+                                Item f0 = t;
+                                f0.kind = TM_P; f0.q0 = tq; f0.q1 = -1;
+                                cls[1 + half].push_back(f0);
+                            }
+                        }
+                        cls[4].clear();
+                    }
+                    auto push_tterm = [&](const Item& t, int type) {
+                        tterms.push_back(TabTerm{type, t.q0, t.q1 >= 0 ? t.q1 : 0, -1});
+                        if (t.expr >= 0) {
+                            tterms.back().tag = (int)tterms.size() - 1;
+                            r_pre(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, PreUser{true, (int)tterms.size() - 1});
+                        }
+                    };
                     int tstart[4];      // RR, lo, hi -> table terms
                     for (int k = 0; k < 3; ++k) {
                         tstart[k] = (int)tterms.size();
-                        for (const Item& t : cls[k]) {
-                            tterms.push_back(TabTerm{t.kind, t.q0, t.q1 >= 0 ? t.q1 : 0, -1});
-                            if (t.expr >= 0) {
-                                tterms.back().tag = (int)tterms.size() - 1;
-                                r_pre(t.expr, t.kind == TM_RZ ? 0.5 : 1.0, PreUser{true, (int)tterms.size() - 1});
-                            }
-                        }
+                        for (const Item& t : cls[k]) push_tterm(t, t.kind);
                     }
                     tstart[3] = (int)tterms.size();
+                    int qstart[4][3];
+                    for (int rp = 0; rp < 4; ++rp) {
+                        for (int h = 0; h < 2; ++h) {
+                            qstart[rp][h] = (int)tterms.size();
+                            for (const Item& t : ratio[rp][h]) push_tterm(t, t.kind | kRatio);
+                        }
+                        qstart[rp][2] = (int)tterms.size();
+                    }
                     int start[6] = {0, 0, 0, 0, 0, 0};      // TX, RT -> evaluated per thread
                     for (int k = 3; k < 5; ++k) {
                         start[k] = (int)rterms.size();
@@ -847,6 +890,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                     // held in the running scale: the stage writes its phases instead of multiplying by them
                     if (!rops.empty() && (int)rops.size() == sg.op0 + 1 && rops.back().kind == RG_INIT && (rops.back().flags & 1)) op.flags |= 256;
                     op.tab = tables(tstart[0], tstart[1] - tstart[0], tstart[1], tstart[2] - tstart[1], tstart[2], tstart[3] - tstart[2]) - n_itab;
+                    if (op.flags & 512)      // the ratio tables of the register positions that have any, in order of position
+                        for (int rp = 0; rp < RB; ++rp)
+                            if ((op.flags >> rp) & 1) thread_tables(qstart[rp][0], qstart[rp][1] - qstart[rp][0], qstart[rp][1], qstart[rp][2] - qstart[rp][1]);
                     op.t0 = start[3];
                     op.nTX = start[4] - start[3];
                     op.nRT = start[5] - start[4];
@@ -912,11 +958,16 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             const int first = (int)tts.size();
             for (int k = 0; k < tb.nt; ++k) {
                 const TabTerm& t = tterms[tb.t0 + k];
-                RegTabTerm r{t.type == TM_CZ ? -1 : t.tag, 0u};
+                RegTabTerm r{(t.type & 0xff) == TM_CZ ? -1 : t.tag, 0u};
                 for (uint32_t x = 0; x < (1u << tb.nbits); ++x) {
                     uint32_t w = tb.fixed;
                     for (int b = 0; b < tb.nbits; ++b) w |= ((x >> b) & 1u) << tb.bits[b];
                     const uint32_t ba = (w >> t.va) & 1u, bb = (w >> t.vb) & 1u;
+                    if (t.type & 0x100) {      // a ratio table's term (va: the thread qubit)
+                        if ((t.type & 0xff) == TM_CZ) { if (ba) r.masks |= 1u << x; }
+                        else r.masks |= (1u << x) | (ba ? 1u << (16 + x) : 0u);      // exp(i theta) / exp(-i theta)
+                        continue;
+                    }
                     const bool on = t.type == TM_RZ || (t.type == TM_P ? ba != 0u : (t.type == TM_CZ ? (ba & bb) != 0u : (ba ^ bb) != 0u));
                     if (on) r.masks |= 1u << x;
                     if (t.type == TM_RZ && !ba) r.masks |= 1u << (16 + x);
@@ -986,13 +1037,31 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             c.plan_summary += "; register-resident plan: " + std::to_string(segs.size()) + " segments, " + std::to_string(rops.size()) +
                               " ops, " + std::to_string(tabs.size()) + " tables, " + std::to_string(n_samp) + " samples per workgroup of " +
                               std::to_string(1 << (Lv - RB)) + " threads";
+            int n_ratio = 0;
+            for (const RegOp& o : rops)
+                if (o.kind == RG_DIAG && (o.flags & 512)) n_ratio += __builtin_popcount((unsigned)o.flags & 15u);
+            if (n_ratio) c.plan_summary += ", ratio tables for " + std::to_string(n_ratio) + " register positions";
         }
         return true;
+    };
+    // ... with the ratio tables of the register-thread terms unless their LDS costs more than a quarter of the resident
+    // workgroups (QK_REG_QTAB=0 / 1: A/B runs)
+    auto plan_q = [&](const int Lv, const size_t lds_limit, size_t* dry_lds = nullptr) -> bool {
+        static const int q_env = std::getenv("QK_REG_QTAB") ? std::atoi(std::getenv("QK_REG_QTAB")) : -1;
+        size_t l1 = 0, l0 = 0;
+        q_tables = true;
+        const bool ok1 = q_env != 0 && plan_reg(Lv, lds_limit, &l1);
+        q_tables = false;
+        const bool ok0 = q_env != 1 && plan_reg(Lv, lds_limit, &l0);
+        if (!ok1 && !ok0) return false;
+        auto per_cu = [](size_t l) { return ((size_t)160 * 1024) / (l & (((size_t)1 << 40) - 1)); };
+        q_tables = ok1 && (!ok0 || 4 * per_cu(l1) >= 3 * per_cu(l0));      // (10 qubits ZZ r = 2, full entanglement: 6 workgroups per CU instead of 7, 5.11 -> 3.22 ms)
+        return plan_reg(Lv, lds_limit, dry_lds);
     };
     if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1 && c.passes[0].L == n) {
         // (QK_REG_LV = 12 at 10 or 11 qubits: four or two samples per workgroup of 256 threads, A/B runs)
         static const int lv_wide = std::getenv("QK_REG_LV") ? std::atoi(std::getenv("QK_REG_LV")) : 0;
-        if (!(lv_wide > n && lv_wide <= kRegPackMaxWidth && plan_reg(lv_wide, (size_t)160 * 1024))) plan_reg(n, (size_t)160 * 1024);
+        if (!(lv_wide > n && lv_wide <= kRegPackMaxWidth && plan_q(lv_wide, (size_t)160 * 1024))) plan_q(n, (size_t)160 * 1024);
     } else if (n >= kRegPackMinQubits && n < kRegMinQubits && c.passes.size() == 1 && c.passes[0].L == n) {
         // The width that keeps the most waves resident on a CU (LDS per workgroup against 3 waves per SIMD at 147 VGPRs);
         // among equals the narrowest workgroup, whose barriers cost least (9 qubits, GA genome: 3.9 ms at L = 10 with five
@@ -1000,11 +1069,11 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         // QK_REG_LV forces one (A/B runs).
         static const int lv_env = std::getenv("QK_REG_LV") ? std::atoi(std::getenv("QK_REG_LV")) : 0;
         bool done = false;
-        if (lv_env >= kRegMinQubits && lv_env <= kRegPackMaxWidth) done = plan_reg(lv_env, (size_t)160 * 1024);
+        if (lv_env >= kRegMinQubits && lv_env <= kRegPackMaxWidth) done = plan_q(lv_env, (size_t)160 * 1024);
         int best = 0, best_waves = 0;
         for (int Lv = kRegMinQubits; Lv <= kRegPackMaxWidth && !done; ++Lv) {
             size_t lds = 0;
-            if (!plan_reg(Lv, (size_t)160 * 1024, &lds)) continue;
+            if (!plan_q(Lv, (size_t)160 * 1024, &lds)) continue;
             // a first layer that is not all Hadamards (GA genomes) has its product-state tables built inside the kernel, a
             // wave per sample and a barrier behind it: single-wave workgroups (L = 10) keep that wave-local
             if (((lds >> 40) & 1) && n >= 7) { best = Lv; break; }      // (6 qubits and below: 16+ samples per wave either way, the count decides)
@@ -1012,7 +1081,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             const int waves = std::min(rb == 3 ? 16 : 12, (int)((size_t)160 * 1024 / (lds & (((size_t)1 << 40) - 1))) * ((1 << (Lv - rb)) / 64));
             if (waves > best_waves) { best_waves = waves; best = Lv; }
         }
-        if (!done && best) plan_reg(best, (size_t)160 * 1024);
+        if (!done && best) plan_q(best, (size_t)160 * 1024);
     }
     return QK_OK;
 }

@@ -580,6 +580,26 @@ hadamard_pos<0, NA>(v);
                         scale = 1.0;
                         for (int k = 0; k < nTX; ++k) bt = cmul(bt, term_factor(term_at(rts_a, cs_l, sbits, t0 + k), wt));
                         v2d r0 = (v2d){1.0, 0.0}, r1 = r0, r2 = r0, r3 = r0;
+                        if (o_flags & 512) {
+                            // The terms between a register qubit and a thread qubit come ready-made: per register position
+                            // what flipping that bit multiplies the phase by, as a product of a table over the low and one
+                            // over the high thread bits (behind the stage's own three tables, in order of position).
+                            const uint32_t hs = n_hi > 4 ? 1u << (n_hi - 4) : (n_hi > 0 ? 1u : 0u);      // slots of the high-bits table
+                            uint32_t qa = ta + 256u * (2u + hs);
+                            auto ratio = [&](uint32_t at) __attribute__((always_inline)) {
+                                if constexpr (PACK) {
+                                    v2d q = ldsr<v2d>(at + 16u * ((uint32_t)tid & ((1u << n_lo) - 1u)));
+                                    if (n_hi > 0) q = cmul(q, ldsr<v2d>(at + 256u + 16u * (((uint32_t)tid >> 4) & ((1u << n_hi) - 1u))));
+                                    return q;
+                                } else {
+                                    return cmul(ldsr<v2d>(at + 16u * ((uint32_t)tid & 15u)), ldsr<v2d>(at + 256u + 16u * ((uint32_t)tid >> 4)));
+                                }
+                            };
+                            if (rtmask & 1) { r0 = ratio(qa); qa += 256u * (1u + hs); }
+                            if (rtmask & 2) { r1 = ratio(qa); qa += 256u * (1u + hs); }
+                            if (rtmask & 4) { r2 = ratio(qa); qa += 256u * (1u + hs); }
+                            if (rtmask & 8) { r3 = ratio(qa); }
+                        }
                         for (int k = 0; k < nRT; ++k) {
                             const TermL t = term_at(rts_a, cs_l, sbits, t0 + nTX + k);
                             const int rp = uni(t.rpos);

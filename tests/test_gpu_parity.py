@@ -286,6 +286,32 @@ def test_register_resident_simulator_packed_samples(n, seed, N, gates):
         assert np.abs(dc.simulate(Xd[:small].contiguous()).cpu().numpy() - ref[:small]).max() < TOL_PSI
 
 
+@pytest.mark.parametrize("n,N", [(8, 16384 + 9), (9, 8192 + 5), (10, 4096 + 3), (11, 900), (12, 700), (13, 300)])
+def test_register_resident_ratio_tables(n, N):
+    """Diagonal stages with many terms between register and thread qubits (ZZ map with full entanglement, r = 2, plus a
+    CZ between every qubit and the last one): the planner turns those terms into ratio tables per register position
+    (qk_circuit.cpp, section 4; 13 qubits: the high-bits tables come in two slots), the kernel multiplies them into its
+    Gray-code walk.  Batches large enough for the default policy to take the register path; rows sampled against the
+    oracle, every row's norm."""
+    import torch
+    from quake_amd import device as qdev, featuremaps as fm
+    x = qc.ParameterVector("x", n)
+    c = fm.zz_featuremap(x, n, 2, entanglement="full")
+    for q in range(n - 1):
+        c.cz(q, n - 1)
+    dc = qdev.DeviceCircuit(c)
+    assert "register-resident plan" in dc.handle.plan_summary, dc.handle.plan_summary
+    # (packed samples, 9 qubits and below: the tables of all the samples of a workgroup would cost resident workgroups;
+    # the planner keeps those terms per thread -- the same circuit through the other code path)
+    assert ("ratio tables" in dc.handle.plan_summary) == (n >= 10), dc.handle.plan_summary
+    X = synth_X(N, n, "scaled", 1300 + n)
+    psi = dc.simulate(torch.from_numpy(X).cuda())
+    rows = np.unique(np.concatenate([[0, 1, N - 2, N - 1], np.random.default_rng(n).integers(0, N, 6)]))
+    assert np.abs(psi[torch.from_numpy(rows).cuda()].cpu().numpy() - psi_from_compiled(c, X[rows])).max() < TOL_PSI
+    assert float(((psi.real ** 2 + psi.imag ** 2).sum(dim=1) - 1.0).abs().max()) < 1e-12
+    del psi
+
+
 def test_register_resident_simulator_in_chunks():
     """A batch whose pre-pass tables would exceed 1 GiB goes through the register-resident path in chunks of whole sample
     groups (6 qubits, ZZ r = 2: 1376 bytes of angles and tables per sample, 800 003 samples = a chunk of 2^30 / 1376 samples rounded down to whole groups and the rest, the second one

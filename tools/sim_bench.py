@@ -34,7 +34,8 @@ def circuits(n):
             extra["genome_g8"] = g
     return {"h_only": h, "z_r1": hp, "z_r2": fm.z_featuremap(x, n, 2), "zz_r1": fm.zz_featuremap(x, n, 1), "zz_r2": fm.zz_featuremap(x, n, 2),
             "custom1_r1": fm.custom1_featuremap(x, n, 1), "custom2_r1": fm.custom2_featuremap(x, n, 1),
-            "custom1_r2": fm.custom1_featuremap(x, n, 2), "custom2_r2": fm.custom2_featuremap(x, n, 2), **extra}
+            "custom1_r2": fm.custom1_featuremap(x, n, 2), "custom2_r2": fm.custom2_featuremap(x, n, 2),
+            "zz_full_r2": fm.zz_featuremap(x, n, 2, entanglement="full"), **extra}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--qubits", type=int, nargs="+", default=[16, 13, 12, 10, 8])
