@@ -612,28 +612,44 @@ hadamard_pos<0, NA>(v);
                             else if (rp == 2) r2 = cmul(r2, q);
                             else r3 = cmul(r3, q);
                         }
-                        if (rtmask == 0) {
+                        // The sixteen entries of the register table, all in flight before the first is used; then the phase
+                        // of every register state by a Gray-code walk over the register bits -- one multiplication by a
+                        // position's ratio (or its conjugate: unit modulus) where that bit flips and the stage has terms on
+                        // it (wave-uniform: a branch per step, not a select between two products) -- and the amplitudes
+                        // multiplied in place, stage by stage over all of them (see the butterflies above).
+                        v2d ph[NA];
 #pragma unroll
-                            for (int k = 0; k < NA; ++k) {
-                                const v2d ph = cmul(bt, ldsr<v2d>(ta + 16u * k));
-                                v[k] = fresh ? ph : cmul(v[k], ph);
-                            }
-                        } else {
-                            // Gray-code walk over the register bits: one multiplication by a ratio (or its conjugate) per step
-                            v2d X = bt;
+                        for (int k = 0; k < NA; ++k) ph[k] = ldsr<v2d>(ta + 16u * k);
+                        {
+                            double Xx = bt.x, Xy = bt.y;
 #pragma unroll
                             for (int i = 0; i < NA; ++i) {
                                 const int g = i ^ (i >> 1);
                                 if (i > 0) {
                                     const int b = __builtin_ctz(i);
                                     if ((rtmask >> b) & 1) {
+                                        asm volatile("" : "+v"(Xx), "+v"(Xy));      // (keeps the branch: nothing here may be computed speculatively)
                                         const v2d q = b == 0 ? r0 : (b == 1 ? r1 : (b == 2 ? r2 : r3));
-                                        X = ((g >> b) & 1) ? cmul(X, q) : cmulc(X, q);
+                                        const v2d X2 = ((g >> b) & 1) ? cmul((v2d){Xx, Xy}, q) : cmulc((v2d){Xx, Xy}, q);
+                                        Xx = X2.x; Xy = X2.y;
                                     }
                                 }
-                                const v2d ph = cmul(X, ldsr<v2d>(ta + 16u * g));
-                                v[g] = fresh ? ph : cmul(v[g], ph);
+                                ph[g] = cmul((v2d){Xx, Xy}, ph[g]);
                             }
+                        }
+                        if (fresh) {
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) v[k] = ph[k];
+                        } else {
+                            double t[NA];
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) t[k] = v.re[k] * ph[k].y;
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) ip_mul<true>(v.re[k], ph[k].x, t[k]);
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) ip_fma_acc<true, true>(v.re[k], ph[k].y, v.im[k]);
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) ip_fma_self<true>(v.im[k], ph[k].x, t[k], v.re[k], v.re[k], v.re[k]);
                         }
                     }
                 } else if (kind == RG_CX) {
