@@ -977,7 +977,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             tb.t0 = first;
         }
         const bool fits = (int)tabs.size() <= kRegMaxTabs && (int)rterms.size() <= kRegMaxTerms && (int)rmats.size() <= std::min(kRegMaxMats, 255);
-        // LDS: the transpose image; the terms evaluated per thread; per sample the product-state tables (unless all-Hadamard);
+        // LDS: the transpose image; per sample the product-state tables (unless all-Hadamard);
         // two buffers each of a group's stage tables + matrices (from the pre-pass kernels) and of its angles; staged records
         const size_t n_dtab = tabs.size() - (size_t)n_itab, n_itab_built = all_h ? 0 : (size_t)n_itab;
         const size_t n_slot = ((size_t)n_samp * n_expr_k + 63) / 64 * 64;      // slots of 64 (cos, sin) pairs
@@ -985,7 +985,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         const size_t t_slot = (side_piece + 63) / 64;
         // (the tables and matrices of the NEXT group arrive while this one computes: two buffers -- one, filled at the top
         // of a group's turn, when two do not fit even a lone workgroup per CU: deep circuits at 13 qubits)
-        const size_t lds_but_side = ((size_t)16 << Lv) + 16 * rterms.size() + (size_t)n_samp * 256 * n_itab_built + 32 * (size_t)n_itab +
+        const size_t lds_but_side = ((size_t)16 << Lv) + (size_t)n_samp * 256 * n_itab_built + 32 * (size_t)n_itab +
                                     4 * (size_t)n + 64 + 32 * n_slot;
         const bool tab_single = lds_but_side + 2048 * t_slot > lds_limit && lds_limit >= (size_t)160 * 1024;
         const size_t lds = lds_but_side + (tab_single ? 1024 : 2048) * t_slot;
@@ -1044,7 +1044,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         }
         return true;
     };
-    // ... with the ratio tables of the register-thread terms unless their LDS costs more than a quarter of the resident
+    // ... with the ratio tables of the register-thread terms unless their LDS costs more than a third of the resident
     // workgroups (QK_REG_QTAB=0 / 1: A/B runs)
     auto plan_q = [&](const int Lv, const size_t lds_limit, size_t* dry_lds = nullptr) -> bool {
         static const int q_env = std::getenv("QK_REG_QTAB") ? std::atoi(std::getenv("QK_REG_QTAB")) : -1;
@@ -1055,7 +1055,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         const bool ok0 = q_env != 1 && plan_reg(Lv, lds_limit, &l0);
         if (!ok1 && !ok0) return false;
         auto per_cu = [](size_t l) { return ((size_t)160 * 1024) / (l & (((size_t)1 << 40) - 1)); };
-        q_tables = ok1 && (!ok0 || 4 * per_cu(l1) >= 3 * per_cu(l0));      // (10 qubits ZZ r = 2, full entanglement: 6 workgroups per CU instead of 7, 5.11 -> 3.22 ms)
+        q_tables = ok1 && (!ok0 || 3 * per_cu(l1) >= 2 * per_cu(l0));      // (10 qubits ZZ r = 2, full entanglement: 6 workgroups per CU instead of 7, 5.11 -> 3.22 ms)
         return plan_reg(Lv, lds_limit, dry_lds);
     };
     if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1 && c.passes[0].L == n) {

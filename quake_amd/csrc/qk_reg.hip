@@ -87,20 +87,24 @@ template <class T> __device__ __forceinline__ T ldsr(uint32_t addr) { return *(c
 template <class T> __device__ __forceinline__ void ldsw(uint32_t addr, T v) { *(__attribute__((address_space(3))) T*)(size_t)addr = v; }
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef int int2v __attribute__((ext_vector_type(2)));
-struct TermL { double c, s; int type, va, vb, rpos; };
-// term t: its record (staged RegTerm) and the (cos, sin) of its angle for this lane's sample (cs_l: the lane's base in the
-// angle buffer, sb = log2 of the samples per group)
-__device__ __forceinline__ TermL term_at(uint32_t rts_a, uint32_t cs_l, int sb, int t) {
-    const int4v k = ldsr<int4v>(rts_a + 16u * (uint32_t)t);
-    const v2d cs = ldsr<v2d>(cs_l + ((uint32_t)(k.w < 0 ? 0 : k.w) << (4 + sb)));
-    return TermL{k.w < 0 ? -1.0 : cs.x, k.w < 0 ? 0.0 : cs.y, k.x & 255, k.y, k.z, k.x >> 8};
+// A term a thread evaluates itself (RegTerm, 16 B): the record comes from the plan by scalar loads, one term ahead, so
+// what kind of term it is and which bits it looks at are wave-uniform scalars; per lane: the bits and the (cos, sin) of
+// the lane's sample (cs_l: the lane's base in the angle buffer, sb = log2 of the samples per group).
+struct TermS { int type, va, vb, rpos, expr; };
+__device__ __forceinline__ TermS term_rec(CWords c_term, int t) {
+    const int x = c_term[4 * t], va = c_term[4 * t + 1], vb = c_term[4 * t + 2], e = c_term[4 * t + 3];
+    return TermS{x & 255, va, vb, x >> 8, e};
 }
-__device__ __forceinline__ v2d term_factor(const TermL& t, uint32_t w) {
+__device__ __forceinline__ v2d term_cs(const TermS& t, uint32_t cs_l, int sb) {
+    const v2d cs = ldsr<v2d>(cs_l + ((uint32_t)(t.expr < 0 ? 0 : t.expr) << (4 + sb)));
+    return t.expr < 0 ? (v2d){-1.0, 0.0} : cs;
+}
+__device__ __forceinline__ v2d term_factor(const TermS& t, v2d cs, uint32_t w) {
     const uint32_t ba = (w >> t.va) & 1u, bb = (w >> t.vb) & 1u;
     const bool rz = t.type == TM_RZ;
     const bool on = rz || (t.type == TM_P ? ba != 0u : (t.type == TM_CZ ? (ba & bb) != 0u : (ba ^ bb) != 0u));
-    const double s = (rz && !ba) ? -t.s : t.s;
-    return (v2d){on ? t.c : 1.0, on ? s : 0.0};
+    const double sn = (rz && !ba) ? -cs.y : cs.y;
+    return (v2d){on ? cs.x : 1.0, on ? sn : 0.0};
 }
 
 __device__ __forceinline__ uint32_t swz(uint32_t i) { return i ^ ((i >> 4) & 15u) ^ ((i >> 8) & 15u) ^ ((i >> 12) & 15u); }
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(1 << TBN) __attribute__((amdgpu_waves_per_eu(R
     const int nq = PACK ? hw[21] : L;                  // qubits of the circuit
     const int sbits = L - nq, S = 1 << sbits;           // samples per workgroup
     static_assert(offsetof(RegHeader, nq) == 84, "RegHeader is read word by word");
-    const int n_seg = hw[1], n_term = hw[4], n_mat = hw[6], init_h = hw[9];
+    const int n_seg = hw[1], n_mat = hw[6], init_h = hw[9];
     const int n_itab = hw[24], n_dtab = hw[3] - hw[24], n_expr = hw[27];      // n_expr: the angle programs the simulator reads itself
     const int off_seg = hw[10], off_op = hw[11], off_tab = hw[12], off_term = hw[13], off_init = hw[18];
     const double init_c = ((const double*)(a.blob + 88))[0];
@@ -353,19 +357,17 @@ __global__ void __launch_bounds__(1 << TBN) __attribute__((amdgpu_waves_per_eu(R
     const int t_piece = (S * n_dtab) << 4, side_piece = t_piece + ((S * n_mat) << 2);      // 16-byte pieces of a group's tables (+ matrices)
     const uint32_t side_bytes = (uint32_t)((side_piece + 63) & ~63) << 4;               // one buffer: whole fetch instructions of 64 pieces
     const uint32_t state_a = (uint32_t)(size_t)(lptr_t)lds;
-    const uint32_t rts_a = state_a + (16u << L);                    // RegTerm records, 16 B
-    const uint32_t itab_a = rts_a + 16u * (uint32_t)n_term;         // 256 B per table
+    const uint32_t itab_a = state_a + (16u << L);                   // 256 B per table
     const uint32_t side_a = itab_a + itab_s * (uint32_t)S;
     const uint32_t stab_a = side_a + (side_single ? 1u : 2u) * side_bytes;      // RegTab records of the product-state tables, 32 B
     const uint32_t init_a = stab_a + 32u * (uint32_t)n_itab;
     const int n_slot = (n_expr * S + 63) & ~63;                     // one slot of 64 pairs per fetch instruction; pair e * S + s
     const uint32_t cs_a = (init_a + 4u * (uint32_t)nq + 15u) & ~15u;   // two buffers of n_slot (cos, sin) pairs
-    const CWords c_seg = cwords(a.blob + off_seg), c_op = cwords(a.blob + off_op);
+    const CWords c_seg = cwords(a.blob + off_seg), c_op = cwords(a.blob + off_op), c_term = cwords(a.blob + off_term);
     const int tid0 = threadIdx.x;
     if (state_a & ((16u << L) - 1u)) __builtin_trap();      // the swizzled image must start where its address bits are clear (dynamic LDS starts at 0)
 
     // ---- once per workgroup: what does not depend on the sample -----------------------------------------------
-    for (int t = tid0; t < 4 * n_term; t += T) ldsw<int>(rts_a + 4u * t, ((const int32_t*)(a.blob + off_term))[t]);
     for (int t = tid0; t < 8 * n_itab; t += T) ldsw<int>(stab_a + 4u * t, ((const int32_t*)(a.blob + off_tab))[t]);
     for (int q = tid0; q < nq; q += T) ldsw<int>(init_a + 4u * q, ((const int32_t*)(a.blob + off_init))[q]);
 
@@ -555,6 +557,16 @@ hadamard_pos<0, NA>(v);
                 } else if (kind == RG_DIAG || kind == RG_INIT) {
                     const int tb0 = o_tab;
                     const uint32_t ta = (kind == RG_INIT ? itab_l : dtab_l) + 256u * (uint32_t)tb0;      // table A: the register bits
+                    // the sixteen entries of the register table: on their way before anything else of the stage, so that the
+                    // waits below (thread tables, terms) cover them as well
+                    v2d ph[NA];
+                    if (kind == RG_DIAG || !(o_flags & 1)) {
+#pragma unroll
+                        for (int k = 0; k < NA; ++k) ph[k] = ldsr<v2d>(ta + 16u * k);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NA; ++k) ph[k] = (v2d){1.0, 0.0};
+                    }
                     v2d bt;
                     if constexpr (PACK) {      // the thread's bits above the circuit's qubits number the sample: not part of the table index
                         bt = ldsr<v2d>(ta + 256u + 16u * ((uint32_t)tid & ((1u << n_lo) - 1u)));
@@ -571,14 +583,34 @@ hadamard_pos<0, NA>(v);
                             scale = init_c;
                         } else {
 #pragma unroll
-                            for (int k = 0; k < NA; ++k) v[k] = cmul(bt, ldsr<v2d>(ta + 16u * k));
+                            for (int k = 0; k < NA; ++k) v[k] = cmul(bt, ph[k]);
                         }
                     } else {
                         const int t0 = o_t0, nTX = o_ntx, nRT = o_nrt, rtmask = o_flags & 15;
                         const bool fresh = (o_flags & 256) != 0;      // the state is the identity times the running scale: write, do not multiply
                         bt = (v2d){bt.x * scale, bt.y * scale};
                         scale = 1.0;
-                        for (int k = 0; k < nTX; ++k) bt = cmul(bt, term_factor(term_at(rts_a, cs_l, sbits, t0 + k), wt));
+                        // terms between thread qubits of different tables, then terms between a register and a thread qubit (unless
+                        // those came as ratio tables): record and angle of the next term are on their way while one is computed
+                        const int nT = nTX + nRT, t_last = t0 + (nT > 0 ? nT - 1 : 0);
+                        TermS tr1 = TermS{0, 0, 0, 0, -1}, tr2 = tr1;
+                        v2d tc1 = (v2d){1.0, 0.0};
+                        if (nT > 0) {
+                            tr1 = term_rec(c_term, t0);
+                            tr2 = term_rec(c_term, t0 + 1 < t_last ? t0 + 1 : t_last);
+                            tc1 = term_cs(tr1, cs_l, sbits);
+                        }
+                        auto next_term = [&](int k, TermS& t, v2d& cs) __attribute__((always_inline)) {
+                            t = tr1; cs = tc1;
+                            tr1 = tr2;
+                            tr2 = term_rec(c_term, t0 + k + 2 < t_last ? t0 + k + 2 : t_last);
+                            tc1 = term_cs(tr1, cs_l, sbits);
+                        };
+                        for (int k = 0; k < nTX; ++k) {
+                            TermS t; v2d cs;
+                            next_term(k, t, cs);
+                            bt = cmul(bt, term_factor(t, cs, wt));
+                        }
                         v2d r0 = (v2d){1.0, 0.0}, r1 = r0, r2 = r0, r3 = r0;
                         if (o_flags & 512) {
                             // The terms between a register qubit and a thread qubit come ready-made: per register position
@@ -601,10 +633,11 @@ hadamard_pos<0, NA>(v);
                             if (rtmask & 8) { r3 = ratio(qa); }
                         }
                         for (int k = 0; k < nRT; ++k) {
-                            const TermL t = term_at(rts_a, cs_l, sbits, t0 + nTX + k);
-                            const int rp = uni(t.rpos);
+                            TermS t; v2d cs;
+                            next_term(nTX + k, t, cs);
+                            const int rp = t.rpos;
                             const uint32_t gb = rp == 0 ? 1u << g0 : (rp == 1 ? 1u << g1 : (rp == 2 ? 1u << g2 : 1u << g3));
-                            const v2d f0 = term_factor(t, wt), f1 = term_factor(t, wt | gb);
+                            const v2d f0 = term_factor(t, cs, wt), f1 = term_factor(t, cs, wt | gb);
                             bt = cmul(bt, f0);
                             const v2d q = cmulc(f1, f0);      // unit modulus: f1 / f0
                             if (rp == 0) r0 = cmul(r0, q);
@@ -612,14 +645,11 @@ hadamard_pos<0, NA>(v);
                             else if (rp == 2) r2 = cmul(r2, q);
                             else r3 = cmul(r3, q);
                         }
-                        // The sixteen entries of the register table, all in flight before the first is used; then the phase
-                        // of every register state by a Gray-code walk over the register bits -- one multiplication by a
+                        QK_RMARK(10);
+                        // The phase of every register state by a Gray-code walk over the register bits -- one multiplication by a
                         // position's ratio (or its conjugate: unit modulus) where that bit flips and the stage has terms on
                         // it (wave-uniform: a branch per step, not a select between two products) -- and the amplitudes
                         // multiplied in place, stage by stage over all of them (see the butterflies above).
-                        v2d ph[NA];
-#pragma unroll
-                        for (int k = 0; k < NA; ++k) ph[k] = ldsr<v2d>(ta + 16u * k);
                         {
                             double Xx = bt.x, Xy = bt.y;
 #pragma unroll
@@ -904,7 +934,7 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
             for (int k = 0; k < 12; ++k) sum[k] += h[12 * b + k];
         std::fprintf(stderr, "[reg trace] L=%d nq=%d RB=%d blocks=%lld groups=%.0f us per sample group and workgroup:", L, H->nq, RB, (long long)nblocks, sum[7]);
         const char* names[12] = {"wait for angles", "segment setup", "transpose read", "init/diag ops", "u1 ops", "other ops", "transpose write / stores", "",
-                                 "barrier", "issue next fetch", "-", "product-state tables"};
+                                 "barrier", "issue next fetch", "diag: terms", "product-state tables"};
         for (int k = 0; k < 12; ++k)
             if (k != 7) std::fprintf(stderr, " %s %.2f", names[k], sum[k] / sum[7] * 0.01);
         std::fprintf(stderr, "\n");
