@@ -1315,7 +1315,11 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         const char* e = std::getenv("QK_SIM_PATH");
         return !e ? 0 : (std::strcmp(e, "reg") == 0 ? 1 : (std::strcmp(e, "noreg") == 0 || std::strcmp(e, "lds") == 0 || std::strcmp(e, "wave") == 0 ? -1 : 0));
     }();
-    const bool reg_pays = n >= 11 ? !direct_shape : big;
+    // (where the batch fills the chip for it: 2^20 amplitudes at 6 qubits and below, 2^22 at 7 to 9, 2^23 at 10 -- second
+    // half of round 3, both kernels' latest builds: 2^22 amplitudes, ZZ r = 2: 10 qubits 0.072 ms wave-resident / 0.075
+    // register-resident, 8 qubits 0.101 / 0.069, 6 qubits 0.260 / 0.095; 2^20: 8 qubits 0.043 / 0.046, 6 qubits 0.073 / 0.048)
+    const int reg_from = n <= 6 ? 20 : (n >= 10 ? 23 : 22);
+    const bool reg_pays = n >= 11 ? !direct_shape : ((N >> reg_from) != 0 || (N << n) >= ((int64_t)1 << reg_from));
     if (dt.reg && !rdm_dev && reg_mode >= 0 && (reg_mode > 0 || reg_pays)) {
         const RegHeader* H = (const RegHeader*)c.reg_blob.data();
         // The angles and the stage tables of the batch live in stream order.  Large batches go in chunks of whole sample

@@ -286,7 +286,7 @@ def test_register_resident_simulator_packed_samples(n, seed, N, gates):
         assert np.abs(dc.simulate(Xd[:small].contiguous()).cpu().numpy() - ref[:small]).max() < TOL_PSI
 
 
-@pytest.mark.parametrize("n,N", [(8, 16384 + 9), (9, 8192 + 5), (10, 4096 + 3), (11, 900), (12, 700), (13, 300)])
+@pytest.mark.parametrize("n,N", [(8, 16384 + 9), (9, 8192 + 5), (10, 8192 + 3), (11, 900), (12, 700), (13, 300)])
 def test_register_resident_ratio_tables(n, N):
     """Diagonal stages with many terms between register and thread qubits (ZZ map with full entanglement, r = 2, plus a
     CZ between every qubit and the last one): the planner turns those terms into ratio tables per register position
