@@ -1319,7 +1319,20 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     // half of round 3, both kernels' latest builds: 2^22 amplitudes, ZZ r = 2: 10 qubits 0.072 ms wave-resident / 0.075
     // register-resident, 8 qubits 0.101 / 0.069, 6 qubits 0.260 / 0.095; 2^20: 8 qubits 0.043 / 0.046, 6 qubits 0.073 / 0.048)
     const int reg_from = n <= 6 ? 20 : (n >= 10 ? 23 : 22);
-    const bool reg_pays = n >= 11 ? !direct_shape : ((N >> reg_from) != 0 || (N << n) >= ((int64_t)1 << reg_from));
+    // (10 qubits, the shapes the LDS kernel's one-wave workgroups keep: the product state of an all-Hadamard layer and one
+    // diagonal stage -- ZZ r = 1 1.03 against 1.11 ms per 4 GiB -- and Hadamard layers between diagonal stages of
+    // single-qubit terms only -- Z r = 2 0.84 against 1.03)
+    auto single_qubit_terms_only = [&]() {
+        for (const DevTerm& t : c.terms)
+            if (t.type == TM_CZ || t.type == TM_ZZP) return false;
+        return true;
+    };
+    // (circuits that are a product state altogether -- the maps without entanglement, whose gates the planner multiplies
+    // into one matrix per qubit -- go either way by 15 %: Z r = 2 0.83 on the LDS kernel against 1.03, custom2 r = 2 1.21
+    // against 1.07; they stay on the register path)
+    const bool lds_at_10 = n == 10 && c.passes.size() == 1 &&
+                           ((direct_shape && all_h_init(c.passes[0])) || (h_layers_shape() && single_qubit_terms_only()));
+    const bool reg_pays = n >= 11 ? !direct_shape : (!lds_at_10 && ((N >> reg_from) != 0 || (N << n) >= ((int64_t)1 << reg_from)));
     if (dt.reg && !rdm_dev && reg_mode >= 0 && (reg_mode > 0 || reg_pays)) {
         const RegHeader* H = (const RegHeader*)c.reg_blob.data();
         // The angles and the stage tables of the batch live in stream order.  Large batches go in chunks of whole sample

@@ -19,8 +19,8 @@ done
 step pqkG; timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmcG -o p -- python3 tools/config_bench.py 4 > $O/pmcG.json 2> $O/pmcG.err || exit 1
 step pqkH; timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/pmcH -o p -- python3 tools/config_bench.py 4 > $O/pmcH.json 2> $O/pmcH.err || exit 1
 step configs; timeout -k 10 300 python3 tools/config_bench.py > $O/configs.json 2> $O/configs.err || exit 1
-step simbench; timeout -k 10 300 python3 tools/sim_bench.py --qubits 16 14 13 12 11 10 9 8 7 6 --gib 4 --maps h_only z_r2 zz_r1 zz_r2 custom1_r1 genome_g8 > $O/sim_bench.json 2> $O/sim_bench.err || exit 1
-step simbench_noreg; QK_SIM_PATH=noreg timeout -k 10 300 python3 tools/sim_bench.py --qubits 13 12 11 10 9 8 7 6 --gib 4 --maps h_only z_r2 zz_r1 zz_r2 custom1_r1 genome_g8 > $O/sim_bench_noreg.json 2> $O/sim_bench_noreg.err || exit 1
+step simbench; timeout -k 10 300 python3 tools/sim_bench.py --qubits 16 14 13 12 11 10 9 8 7 6 --gib 4 --maps h_only z_r2 zz_r1 zz_r2 zz_full_r2 custom1_r1 custom1_r2 genome_g8 > $O/sim_bench.json 2> $O/sim_bench.err || exit 1
+step simbench_noreg; QK_SIM_PATH=noreg timeout -k 10 300 python3 tools/sim_bench.py --qubits 13 12 11 10 9 8 7 6 --gib 4 --maps h_only z_r2 zz_r1 zz_r2 zz_full_r2 custom1_r1 custom1_r2 genome_g8 > $O/sim_bench_noreg.json 2> $O/sim_bench_noreg.err || exit 1
 step simtrace; timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/sim_kt -o kt -- python3 tools/sim_bench.py --qubits 12 8 --gib 4 --maps zz_r2 genome_g8 > /dev/null 2> $O/sim_kt.err || exit 1
 step ga; timeout -k 10 100 python3 tools/ga_bench.py > $O/ga_bench.json 2> $O/ga_bench.err || exit 1
 step ga_trace; timeout -k 10 100 rocprofv3 --kernel-trace --stats -d $O/ga_kt -o kt -- python3 tools/ga_bench.py > /dev/null 2> $O/ga_kt.err || exit 1
