@@ -1058,7 +1058,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         q_tables = ok1 && (!ok0 || 3 * per_cu(l1) >= 2 * per_cu(l0));      // (10 qubits ZZ r = 2, full entanglement: 6 workgroups per CU instead of 7, 5.11 -> 3.22 ms)
         return plan_reg(Lv, lds_limit, dry_lds);
     };
-    if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1 && c.passes[0].L == n) {
+    // (one pass of the LDS plan: at 13 qubits that plan prefers 12 local qubits and a chunk bit where a qubit has no butterfly
+    // -- most GA genomes -- which is no obstacle here: the register plan is made from the gate sequence itself)
+    if (n >= kRegMinQubits && n <= kRegMaxQubits && c.passes.size() == 1) {
         // (QK_REG_LV = 12 at 10 or 11 qubits: four or two samples per workgroup of 256 threads, A/B runs)
         static const int lv_wide = std::getenv("QK_REG_LV") ? std::atoi(std::getenv("QK_REG_LV")) : 0;
         if (!(lv_wide > n && lv_wide <= kRegPackMaxWidth && plan_q(lv_wide, (size_t)160 * 1024))) plan_q(n, (size_t)160 * 1024);
