@@ -119,3 +119,49 @@ def test_packed_register_plans_below_ten_qubits():
     assert plan_of(_gate_soup(6, 32, 54))[3:] == (16, 128)      # 8 amplitudes per thread: 16 samples, not 64, share a workgroup
     assert plan_of(_gate_soup(8, 34, 72)) is not None and plan_of(_gate_soup(13, 22, 117)) is not None
     assert plan_of(zz(3, 1)) is None and plan_of(zz(14, 2)) is None          # below 4 qubits / two passes
+
+
+def _reg_plan(circ):
+    s = plan(circ)[0]
+    m = re.search(r"register-resident plan: (\d+) segments, (\d+) ops, (\d+) tables, (\d+) samples per workgroup of (\d+) threads(, ratio tables for (\d+) register positions)?", s)
+    if not m:
+        return None
+    g = m.groups()
+    return {"segments": int(g[0]), "ops": int(g[1]), "tables": int(g[2]), "samples": int(g[3]), "threads": int(g[4]),
+            "ratio_positions": int(g[6]) if g[6] else 0}
+
+
+def test_register_plan_picks_amplitudes_per_thread_by_circuit():
+    """qk_circuit.cpp section 4: the Z / ZZ maps -- diagonal stages and Hadamard layers -- keep 16 amplitudes
+    per thread from 8 qubits on; circuits with a layer's worth of matrix butterflies and swaps (GA genomes) take 8 on
+    twice the threads; 7 qubits and below always 8; a 13-qubit genome whose LDS plan keeps a chunk bit still gets a
+    register plan."""
+    from tests.test_gpu_parity import _gate_soup
+    for n in (8, 10, 12, 13):
+        p = _reg_plan(zz(n, 2))
+        assert p and p["samples"] * (1 << n) == 16 * p["threads"], (n, p)
+    for n in (5, 6, 7):
+        p = _reg_plan(zz(n, 2))
+        assert p and p["samples"] * (1 << n) == 8 * p["threads"], (n, p)
+    for n, seed in ((10, 3), (11, 20), (12, 21)):
+        p = _reg_plan(_gate_soup(n, seed, 4 * n))
+        assert p and p["samples"] == 1 and 8 * p["threads"] == (1 << n), (n, p)      # few diagonal terms, many butterflies
+    gd = {"single_non_parametric": ["Id", "H", "X", "SX"], "single_parametric": ["RX", "RY", "RZ"], "two_non_parametric": ["CX"], "two_parametric": []}
+    genes = genetic.initial_population(1, 13, 8, gd, 13, rng=np.random.default_rng(7))[0]
+    g13, _ = genetic.to_quantum(genes, gd, 13, 8, 13, physical_qubits=list(range(13)), verbose=False)
+    s = plan(g13)[0]
+    assert "pass0 L12" in s and _reg_plan(g13) is not None, s
+
+
+def test_register_plan_ratio_tables_need_many_register_thread_terms():
+    """Terms between a register and a thread qubit become ratio tables from three per register position (full entanglement),
+    not for the linear maps, whose stages have one or two; every register position that has such terms gets its pair of
+    tables (low / high thread bits; at 13 qubits the high-bits table has two slots), counted in the plan's tables."""
+    x12 = ParameterVector("x", 12)
+    full = _reg_plan(fm.zz_featuremap(x12, 12, 2, entanglement="full"))
+    lin = _reg_plan(zz(12, 2))
+    assert lin["ratio_positions"] == 0 and lin["tables"] == 9           # INIT + two stages of (A, Blo, Bhi)
+    assert full["ratio_positions"] == 8 and full["tables"] == 9 + 2 * 8
+    x13 = ParameterVector("x", 13)
+    full13 = _reg_plan(fm.zz_featuremap(x13, 13, 2, entanglement="full"))
+    assert full13["ratio_positions"] == 8 and full13["tables"] == 3 * 4 + 3 * 8      # (A, Blo, 2 x Bhi) and (Qlo, 2 x Qhi) per position
