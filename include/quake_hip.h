@@ -196,6 +196,14 @@ int qk_rdm1_dev(const void* psi_dev, int64_t N, int n_qubits, double* rdm_dev, v
  * the call is qk_simulate_dev + qk_rdm1_dev.
  */
 int qk_simulate_rdm1_is_fused(const qk_circuit* c);
+/*
+ * No counterpart in the reference (a scheduling hint of this library).  1 when a call over N samples should be given the
+ * N x 2^n complex128 workspace: the circuit cannot run fused, or the two-step route is the faster one for this circuit
+ * and batch (circuits the register-resident simulator runs much faster than the LDS simulator: GA genomes, maps with
+ * layers of rotations; at most 8 GiB of workspace).  qk_simulate_rdm1_dev takes the two-step route exactly when this
+ * returns 1 AND the workspace is passed; with a null workspace a circuit that can run fused still does.
+ */
+int qk_simulate_rdm1_wants_workspace(const qk_circuit* c, int64_t N);
 int qk_simulate_rdm1_dev(const qk_circuit* c, const double* X_dev, int64_t N, int64_t ldx,
                          double* rdm_dev, void* psi_ws_dev, void* stream);
 

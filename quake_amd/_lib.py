@@ -72,6 +72,7 @@ SIGNATURES = {
     "qk_evaluate": (C.c_int, [_P, _P, _I64, _P, _I64, C.c_int, _P]),
     "qk_rdm1_dev": (C.c_int, [_P, _I64, C.c_int, _P, _P]),
     "qk_simulate_rdm1_is_fused": (C.c_int, [_P]),
+    "qk_simulate_rdm1_wants_workspace": (C.c_int, [_P, _I64]),
     "qk_simulate_rdm1_dev": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
     "qk_pqk_dev": (C.c_int, [_P, _I64, _P, _I64, C.c_int, C.c_double, _P, _I64, _P]),
     "qk_projected_kernel": (C.c_int, [_P, _P, _I64, C.c_int, C.c_double, _P]),

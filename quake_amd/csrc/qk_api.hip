@@ -494,7 +494,7 @@ extern "C" int qk_projected_kernel(const qk_circuit* c, const double* X, int64_t
     DevBuf dX, dPsi, dR, dK;
     if ((rc = upload_X(X, N, F, dX))) return rc;
     QK_HIP(dR.alloc((size_t)N * n * 4 * sizeof(double)));
-    if (!qk_simulate_rdm1_is_fused(c)) QK_HIP(dPsi.alloc((size_t)N * D * 16));   // fused: Psi is never materialised
+    if (qk_simulate_rdm1_wants_workspace(c, N)) QK_HIP(dPsi.alloc((size_t)N * D * 16));   // fused: Psi is never materialised
     if ((rc = qk_simulate_rdm1_dev(c, (const double*)dX.p, N, F, (double*)dR.p, dPsi.p, nullptr))) return rc;
     QK_HIP(dK.alloc((size_t)N * N * sizeof(double)));
     if ((rc = qk_pqk_dev((const double*)dR.p, N, nullptr, N, n, gamma, (double*)dK.p, N, nullptr))) return rc;

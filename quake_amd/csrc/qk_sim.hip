@@ -1549,13 +1549,51 @@ extern "C" int qk_simulate_c64_dev(const qk_circuit* cc, const double* X_dev, in
     return simulate_impl(cc, X_dev, N, ldx, psi_ws_dev, nullptr, stream, psi32_dev);
 }
 
+// The fused mode reduces from the LDS kernel's image; circuits that the register-resident kernel runs much faster than
+// the LDS kernel are quicker through qk_simulate_dev + qk_rdm1_dev even though Psi is then written and read once
+// (N x 2^n complex128 of workspace).  Measured, fused -> two steps (tools/rdm_route_ab.py): GA genomes 12 qubits x 32768
+// 2.20 -> 1.68 ms, 11 x 65536 3.34 -> 2.04, 10 x 131072 2.61 -> 1.84; custom1 r = 2 at 11 qubits 3.12 -> 2.14; ZZ r = 2 with
+// full entanglement at 12 qubits 2.47 -> 1.96; the ZZ map at r = 1 stays fused at every width (0.87 against 1.25 at 12
+// qubits), at r = 2 from 10 qubits (1.29 against 1.56 at 12; 8 qubits: 2.17 -> 1.81).
+static bool rdm_two_steps_pay(const qk_circuit* cc, int64_t N) {
+    using namespace qk;
+    const qk_circuit& c = *cc;
+    const int n = c.n_qubits;
+    if (c.reg_blob.empty() || c.passes.size() != 1) return false;
+    const int reg_from = n <= 6 ? 20 : (n >= 10 ? 23 : 22);      // (the batch sizes from which simulate_impl takes the register path)
+    if (n < 11 && (N << n) < ((int64_t)1 << reg_from)) return false;
+    if (n >= 11 && (N << n) < ((int64_t)1 << 22)) return false;
+    if (((N << n) >> 29) != 0) return false;      // more than 8 GiB of workspace: stay fused
+    const Pass& ps = c.passes[0];
+    const bool direct_shape = ps.n_init > 0 && ps.n_stage == ps.n_init + 1 && c.stages[ps.stage_off + ps.n_init].kind == ST_DIAG;
+    if (direct_shape || ps.n_stage == ps.n_init) return false;      // product state (+ one diagonal stage): nothing to gain
+    bool h_layers = true;      // diagonal stages and layers of Hadamards only (the maps at r >= 2)
+    for (int k = ps.n_init; k < ps.n_stage && h_layers; ++k) {
+        const DevStage& st = c.stages[ps.stage_off + k];
+        if (st.kind == ST_DIAG) continue;
+        h_layers = st.kind == ST_U1;
+        for (int g = 0; h_layers && g < st.ng; ++g) h_layers = c.mats[ps.mat_off + st.gm[g]].gate == QK_H;
+    }
+    if (!h_layers) return true;
+    const RegHeader* H = (const RegHeader*)c.reg_blob.data();
+    const RegOp* ops = (const RegOp*)((const char*)c.reg_blob.data() + H->off_op);
+    bool ratio = false;
+    for (int k = 0; k < H->n_op; ++k) ratio = ratio || (ops[k].kind == RG_DIAG && (ops[k].flags & 512));
+    return n < 10 || (ratio && n <= 12);      // (13 qubits, ZZ r = 2 with full entanglement: 1.78 fused against 2.73)
+}
+
+extern "C" int qk_simulate_rdm1_wants_workspace(const qk_circuit* c, int64_t N) {
+    if (!c) return 0;
+    return (!qk_simulate_rdm1_is_fused(c) || rdm_two_steps_pay(c, N)) ? 1 : 0;
+}
+
 extern "C" int qk_simulate_rdm1_dev(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx, double* rdm_dev,
                                     void* psi_ws_dev, void* stream) {
     using namespace qk;
     if (!cc || !rdm_dev) return fail(QK_ERR_INVALID, "qk_simulate_rdm1_dev: null circuit or output");
     if (N < 0) return fail(QK_ERR_INVALID, "qk_simulate_rdm1_dev: negative N");
     if (N == 0) return QK_OK;
-    if (qk_simulate_rdm1_is_fused(cc)) return simulate_impl(cc, X_dev, N, ldx, nullptr, rdm_dev, stream);
+    if (qk_simulate_rdm1_is_fused(cc) && !(psi_ws_dev && rdm_two_steps_pay(cc, N))) return simulate_impl(cc, X_dev, N, ldx, nullptr, rdm_dev, stream);
     if (!psi_ws_dev)
         return fail(QK_ERR_INVALID, "qk_simulate_rdm1_dev: this circuit needs a statevector workspace (not fused)");
     const int rc = simulate_impl(cc, X_dev, N, ldx, psi_ws_dev, nullptr, stream);

@@ -100,7 +100,7 @@ def simulate_rdm1(circuit: "DeviceCircuit", X: torch.Tensor) -> torch.Tensor:
     N, n = X.shape[0], circuit.n_qubits
     out = torch.empty((N, n, 4), dtype=torch.float64, device=X.device)
     ws = None
-    if not lib.qk_simulate_rdm1_is_fused(circuit.handle.handle):
+    if lib.qk_simulate_rdm1_wants_workspace(circuit.handle.handle, N):      # not fused, or the two-step route is the faster one
         ws = torch.empty((N, 1 << n), dtype=torch.complex128, device=X.device)
     ldx = X.stride(0) if (N > 1 and X.shape[1]) else max(X.shape[1], 1)
     _lib.check(lib.qk_simulate_rdm1_dev(circuit.handle.handle, _dp(X) if X.numel() else None, N, ldx, _dp(out), _dp(ws),

@@ -97,6 +97,35 @@ def test_fused_simulate_rdm1(n, N, fused):
     assert np.abs(got - two_step).max() < 1e-14      # two simulators (LDS-resident fused path, wave-resident kernel): different rounding
 
 
+@pytest.mark.parametrize("n,N", [(8, 16384 + 5), (10, 8192 + 3), (12, 1024 + 1)])
+def test_simulate_rdm1_two_step_route(n, N):
+    """Circuits the register-resident simulator runs much faster than the LDS one (here: the custom1 map at r = 2, a layer
+    of rotations between entangling diagonal stages) take simulate + rdm1 through a workspace once the batch is large
+    (qk_simulate_rdm1_wants_workspace).  The route the library picks, the fused route (no workspace passed)
+    and the oracle agree; small batches of the same circuit stay fused."""
+    import torch
+    from quake_amd import _lib, device as qdev, featuremaps as fm
+    from quake_amd.circuit import ParameterVector
+    lib = _lib.load()
+    fmap = fm.custom1_featuremap(ParameterVector("x", n), n, 2)
+    circ = qdev.DeviceCircuit(fmap)
+    assert lib.qk_simulate_rdm1_is_fused(circ.handle.handle) == 1
+    assert lib.qk_simulate_rdm1_wants_workspace(circ.handle.handle, N) == 1
+    assert lib.qk_simulate_rdm1_wants_workspace(circ.handle.handle, 64) == 0
+    X = np.random.default_rng(60 + n).uniform(-1.0, 1.0, size=(N, circ.n_params))
+    Xd = torch.from_numpy(X).cuda()
+    got = qdev.simulate_rdm1(circ, Xd)
+    fused = torch.empty_like(got)
+    _lib.check(lib.qk_simulate_rdm1_dev(circ.handle.handle, Xd.data_ptr(), N, Xd.stride(0), fused.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    assert float((got - fused).abs().max()) < 1e-13
+    rows = np.unique(np.concatenate([[0, 1, N - 1], np.random.default_rng(n).integers(0, N, 5)]))
+    from tests._helpers import psi_from_compiled
+    r = O.rdm1(psi_from_compiled(fmap, X[rows]), n)
+    want = np.stack([r[..., 0, 0].real, r[..., 1, 1].real, r[..., 0, 1].real, r[..., 0, 1].imag], axis=-1)
+    assert np.abs(got[torch.from_numpy(rows).cuda()].cpu().numpy() - want).max() < 1e-13
+
+
 def test_k_block_to_host_leg():
     """ShardedGram.compute(K_host=...): the row block also lands in page-locked host memory through
     qk_block_to_host_async on a side stream (strided 2-D copies, no temporaries)."""
