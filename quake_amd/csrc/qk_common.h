@@ -225,7 +225,8 @@ int launch_wave_jobs(const WaveJob* jobs_host, int n_jobs, const WaveJob* table_
 size_t reg_side_bytes(const qk_circuit& c, int64_t N);
 int launch_reg_side(const qk_circuit& c, const void* blob_dev, const double2* cs, int64_t N, void* tabs, hipStream_t stream);
 int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs, const void* tabs, int64_t N, void* psi, void* psi32,
-                   hipStream_t stream);
+                   hipStream_t stream, double* rdm = nullptr);      // rdm: the reduced density matrices instead of Psi (unpacked plans)
+bool reg_rdm_mode_ok(const qk_circuit& c);      // the plan can run in that mode (one sample per workgroup, LDS left for the reduction)
 // qk_sim.hip
 int upload_circuit(qk_circuit& c, DevTables& out);   // the tables of the current device (uploaded on first use)
 void free_circuit_device(qk_circuit& c);

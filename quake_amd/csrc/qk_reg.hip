@@ -36,6 +36,7 @@
 
 #include "qk_common.h"
 #include "qk_reg.h"
+#include "qk_rdm.h"
 
 namespace qk {
 
@@ -51,6 +52,8 @@ struct RegArgs {
     float2* psi32;         // FP32 output: the state is evolved in FP64 and rounded once, at the store
     int64_t D;
     double* trace;         // QK_REG_TRACE builds: 8 doubles per workgroup (100 MHz ticks per phase, summed over its samples)
+    double* rdm;           // not null: instead of Psi, the per-qubit reduced density matrices [sample][qubit][4] (one sample per workgroup)
+    int red_off;           // rdm: byte offset in LDS of the reduction scratch (RDM_SLOTS doubles per wave)
 };
 
 namespace {
@@ -334,7 +337,8 @@ __device__ __forceinline__ void ecr_reg(Amps<NA>& v) {
 // Waves per SIMD, lower and upper bound alike: LDS, not registers, decides how many workgroups a CU holds (two states of 12
 // qubits, seven of 10), so the scheduler is told not to trade instruction-level parallelism for an occupancy the kernel
 // cannot have.
-template <int TBN, int RB, bool PACK>
+// RDM: the reduced-density-matrix mode (a.rdm; its reduction is kept out of the plain kernels' register allocation).
+template <int TBN, int RB, bool PACK, bool RDM = false>
 __global__ void __launch_bounds__(1 << TBN) __attribute__((amdgpu_waves_per_eu(RB == 3 ? 4 : 2, RB == 3 ? 4 : 2))) reg_sim_kernel(RegArgs a) {
     extern __shared__ double2 lds[];
     constexpr int L = TBN + RB, T = 1 << TBN, NA = 1 << RB;
@@ -425,7 +429,8 @@ __global__ void __launch_bounds__(1 << TBN) __attribute__((amdgpu_waves_per_eu(R
         // turn's NA stores of Psi, and memory operations complete in order -- a counted wait, so the stores go on
         // draining under this group's arithmetic (a plain vmcnt(0), which is what a prefetch into registers gets from the
         // compiler, holds the workgroup until the whole statevector of the previous sample has left the chip).
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+        if constexpr (RDM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (no stores of Psi behind the fetch in this mode: wait for everything)
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
         QK_RMARK(0);
         lds_barrier();      // every wave's share of the fetch has landed; every wave is done with the previous group
         QK_RMARK(8);
@@ -716,7 +721,15 @@ hadamard_pos<0, NA>(v);
                     const int64_t last = a.N - 1 - (sample << sbits);      // >= 0
                     if ((int64_t)sid > last) wo = (wt & ((1u << nq) - 1u)) | ((uint32_t)last << nq);
                 }
-                if (a.psi32) {
+                if constexpr (RDM) {
+                    // the projected kernel's mode: the state goes to the image once more, in index order, and the per-qubit
+                    // reduced density matrices are reduced from there (qk_rdm.h, as in the LDS simulator's fused mode);
+                    // Psi is never written.  One sample per workgroup (the host does not take this path for packed plans).
+#pragma unroll
+                    for (int k = 0; k < NA; ++k) ldsw<v2d>(state_a + ((wt | kdep(k)) << 4), v[k]);
+                    __syncthreads();
+                    rdm1_from_lds((const double2*)lds + (state_a >> 4), nq, (double*)((char*)lds + a.red_off), a.rdm + sample * (int64_t)(4 * nq), tid, T);
+                } else if (a.psi32) {
                     char* gp = (char*)(a.psi32 + sample * a.D);
                     uint32_t off = wo << 3;
 #pragma unroll
@@ -836,6 +849,16 @@ __global__ void __launch_bounds__(256) reg_matrix_kernel(const char* blob, const
     o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m3;
 }
 
+bool reg_rdm_mode_ok(const qk_circuit& c) {
+    if (c.reg_blob.empty()) return false;
+    const RegHeader* H = (const RegHeader*)c.reg_blob.data();
+    // (one sample per workgroup; 16 amplitudes per thread: with 8 the workgroup has twice the waves at 128 registers each, and
+    // the reduction -- 16 amplitudes and 16 partial sums per thread -- spills there)
+    if (H->nq != H->L || H->nq > RDM_MAXQ || H->rb != 4) return false;
+    const size_t threads = (size_t)1 << (H->L - H->rb);
+    return (c.reg_lds_bytes + 15) / 16 * 16 + sizeof(double) * RDM_SLOTS * (threads / 64) <= (size_t)160 * 1024;
+}
+
 // bytes of the tables and matrices of a batch of N samples (0: the circuit has neither)
 size_t reg_side_bytes(const qk_circuit& c, int64_t N) {
     const RegHeader* H = (const RegHeader*)c.reg_blob.data();
@@ -861,7 +884,7 @@ int launch_reg_side(const qk_circuit& c, const void* blob_dev, const double2* cs
 }
 
 int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs, const void* tabs, int64_t N, void* psi, void* psi32,
-                   hipStream_t stream) {
+                   hipStream_t stream, double* rdm) {
     const RegHeader* H = (const RegHeader*)c.reg_blob.data();
     const int L = H->L, RB = H->rb;      // L > n_qubits: 2^(L - n_qubits) samples per workgroup
     const bool pack = H->nq < L;
@@ -870,6 +893,8 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
                              {(const void*)reg_sim_kernel<6, 4, false>, (const void*)reg_sim_kernel<7, 4, false>, (const void*)reg_sim_kernel<8, 4, false>, (const void*)reg_sim_kernel<9, 4, false>},
                              {(const void*)reg_sim_kernel<6, 4, true>, (const void*)reg_sim_kernel<7, 4, true>, (const void*)reg_sim_kernel<8, 4, true>, nullptr},
                              {(const void*)reg_sim_kernel<7, 3, true>, (const void*)reg_sim_kernel<8, 3, true>, (const void*)reg_sim_kernel<9, 3, true>, nullptr}};
+    const void* fns_rdm[4] = {(const void*)reg_sim_kernel<6, 4, false, true>, (const void*)reg_sim_kernel<7, 4, false, true>,
+                              (const void*)reg_sim_kernel<8, 4, false, true>, (const void*)reg_sim_kernel<9, 4, false, true>};
     if (H->nq != c.n_qubits || L < kRegMinQubits || L > kRegMaxQubits || (RB != 3 && RB != 4) || (pack && L > kRegPackMaxWidth))
         return fail(QK_ERR_INVALID, "register-resident simulator: malformed plan");
     static DeviceOnce attr_set;
@@ -877,6 +902,7 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
         for (int r = 0; r < 4; ++r)
             for (int k = 0; k < 4; ++k)
                 if (fns[r][k]) QK_HIP(hipFuncSetAttribute(fns[r][k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int k = 0; k < 4; ++k) QK_HIP(hipFuncSetAttribute(fns_rdm[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
     RegArgs a{};
@@ -893,12 +919,19 @@ int launch_reg_sim(const qk_circuit& c, const void* blob_dev, const double2* cs,
     QK_HIP(hipMemsetAsync(trace_buf, 0, 12 * sizeof(double) * 256 * 16, stream));
     a.trace = trace_buf;
 #endif
-    const size_t lds = c.reg_lds_bytes;
     const int threads = 1 << (L - RB);
+    size_t lds = c.reg_lds_bytes;
+    if (rdm) {
+        if (!reg_rdm_mode_ok(c)) return fail(QK_ERR_INVALID, "register-resident simulator: no reduced-density-matrix mode for this plan");
+        a.rdm = rdm;
+        a.red_off = (int)((lds + 15) / 16 * 16);
+        lds = (size_t)a.red_off + sizeof(double) * RDM_SLOTS * (size_t)(threads / 64);
+        if (lds > (size_t)160 * 1024) return fail(QK_ERR_UNSUPPORTED, "register-resident simulator: no LDS left for the reduction");
+    }
     // Resident workgroups per CU, as the runtime counts them for this kernel's registers and this plan's LDS: the grid is
     // exactly what the chip holds at once, every workgroup walking its share of the sample groups.  (Asked, not assumed:
     // a grid sized for fewer workgroups than a CU takes lets the dispatcher fill some CUs and leave others short.)
-    const void* fn = fns[pack ? (RB == 3 ? 3 : 2) : (RB == 3 ? 0 : 1)][L - 10];
+    const void* fn = rdm ? fns_rdm[L - 10] : fns[pack ? (RB == 3 ? 3 : 2) : (RB == 3 ? 0 : 1)][L - 10];
     int per_cu = 0;
     {
         static std::mutex mu;

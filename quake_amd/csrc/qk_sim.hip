@@ -1252,6 +1252,36 @@ static int scratch_alloc(void** out, size_t bytes, hipStream_t stream) {
     return QK_OK;
 }
 
+// diagonal stages and layers of Hadamards only behind the first layer (the maps at r >= 2)
+static bool shape_h_layers(const qk_circuit& c) {
+    if (c.passes.size() != 1) return false;
+    const Pass& ps = c.passes[0];
+    bool layers = false;
+    for (int k = ps.n_init; k < ps.n_stage; ++k) {
+        const DevStage& st = c.stages[ps.stage_off + k];
+        if (st.kind == ST_DIAG) continue;
+        if (st.kind != ST_U1) return false;
+        for (int g = 0; g < st.ng; ++g)
+            if (c.mats[ps.mat_off + st.gm[g]].gate != QK_H) return false;
+        layers = true;
+    }
+    return layers;
+}
+
+// The register-resident kernel in its reduced-density-matrix mode (the projected kernel; unpacked plans with 16 amplitudes
+// per thread: 10 qubits and up) instead of the LDS kernel's fused mode, from 2^22 amplitudes.  Measured, LDS-fused ->
+// register-fused (tools/rdm_route_ab.py): 12 qubits x 32768: ZZ r = 1 0.82 -> 0.66 ms, r = 2 1.17 -> 1.02, custom1 r = 2
+// 2.19 -> 1.32, a genome 1.62 -> 0.93; 11 x 65536: ZZ r = 1 1.27 -> 0.67, r = 2 1.52 -> 1.03; 10 x 131072: ZZ r = 1 1.47 ->
+// 0.76, custom1 r = 2 3.31 -> 1.69 -- but ZZ r = 2 1.63 -> 1.89: Hadamard-layer circuits at 10 qubits keep the LDS kernel.
+static bool reg_rdm_route(const qk_circuit& c, int64_t N) {
+    static const int env = [] { const char* e = std::getenv("QK_RDM_REG"); return e ? std::atoi(e) : -1; }();      // (A/B runs: 0 never, 1 always)
+    static const bool force_reg = [] { const char* e = std::getenv("QK_SIM_PATH"); return e && std::strcmp(e, "reg") == 0; }();
+    if (env == 0 || !reg_rdm_mode_ok(c) || c.passes.size() != 1) return false;
+    if (env == 1 || force_reg) return true;
+    const int n = c.n_qubits;
+    return (N << n) >= ((int64_t)1 << 22) && !(n == 10 && shape_h_layers(c));
+}
+
 // psi32 != null: the last pass writes complex64 there; with several passes psi_dev (complex128) is
 // the workspace the earlier passes go through.
 static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, int64_t ldx, void* psi_dev, double* rdm_dev,
@@ -1333,7 +1363,8 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     const bool lds_at_10 = n == 10 && c.passes.size() == 1 &&
                            ((direct_shape && all_h_init(c.passes[0])) || (h_layers_shape() && single_qubit_terms_only()));
     const bool reg_pays = n >= 11 ? !direct_shape : (!lds_at_10 && ((N >> reg_from) != 0 || (N << n) >= ((int64_t)1 << reg_from)));
-    if (dt.reg && !rdm_dev && reg_mode >= 0 && (reg_mode > 0 || reg_pays)) {
+    const bool reg_rdm = rdm_dev && dt.reg && reg_rdm_route(c, N);      // (its reduced-density-matrix mode: see reg_rdm_route)
+    if (dt.reg && reg_mode >= 0 && (rdm_dev ? reg_rdm : (reg_mode > 0 || reg_pays))) {
         const RegHeader* H = (const RegHeader*)c.reg_blob.data();
         // The angles and the stage tables of the batch live in stream order.  Large batches go in chunks of whole sample
         // groups so that those tables stay within 1 GiB whatever N is.
@@ -1358,7 +1389,9 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
                 rc = scratch_alloc(&tabs, tb, (hipStream_t)stream);
                 if (rc == QK_OK) rc = launch_reg_side(c, dt.reg, cs, Nc, tabs, (hipStream_t)stream);
             }
-            if (rc == QK_OK)
+            if (rc == QK_OK && rdm_dev)
+                rc = launch_reg_sim(c, dt.reg, cs, tabs, Nc, nullptr, nullptr, (hipStream_t)stream, rdm_dev + s0 * (int64_t)(4 * n));
+            else if (rc == QK_OK)
                 rc = launch_reg_sim(c, dt.reg, cs, tabs, Nc, psi32_dev ? nullptr : (void*)((double2*)psi_dev + (s0 << n)),
                                     psi32_dev ? (void*)((float2*)psi32_dev + (s0 << n)) : nullptr, (hipStream_t)stream);
             if (cs) (void)hipFreeAsync(cs, (hipStream_t)stream);
@@ -1560,6 +1593,7 @@ static bool rdm_two_steps_pay(const qk_circuit* cc, int64_t N) {
     const qk_circuit& c = *cc;
     const int n = c.n_qubits;
     if (c.reg_blob.empty() || c.passes.size() != 1) return false;
+    if (qk_simulate_rdm1_is_fused(cc) && reg_rdm_route(cc->rdm_plan ? *cc->rdm_plan : c, N)) return false;      // fused in the register kernel: faster still
     const int reg_from = n <= 6 ? 20 : (n >= 10 ? 23 : 22);      // (the batch sizes from which simulate_impl takes the register path)
     if (n < 11 && (N << n) < ((int64_t)1 << reg_from)) return false;
     if (n >= 11 && (N << n) < ((int64_t)1 << 22)) return false;

@@ -97,30 +97,32 @@ def test_fused_simulate_rdm1(n, N, fused):
     assert np.abs(got - two_step).max() < 1e-14      # two simulators (LDS-resident fused path, wave-resident kernel): different rounding
 
 
-@pytest.mark.parametrize("n,N", [(8, 16384 + 5), (10, 8192 + 3), (12, 1024 + 1)])
-def test_simulate_rdm1_two_step_route(n, N):
-    """Circuits the register-resident simulator runs much faster than the LDS one (here: the custom1 map at r = 2, a layer
-    of rotations between entangling diagonal stages) take simulate + rdm1 through a workspace once the batch is large
-    (qk_simulate_rdm1_wants_workspace).  The route the library picks, the fused route (no workspace passed)
-    and the oracle agree; small batches of the same circuit stay fused."""
+@pytest.mark.parametrize("n,N,workspace", [(8, 16384 + 5, 1), (10, 8192 + 3, 0), (12, 1024 + 1, 0), (13, 512 + 1, 0)])
+def test_simulate_rdm1_routes(n, N, workspace):
+    """The three routes of qk_simulate_rdm1_dev on a circuit with a layer of rotations between entangling diagonal stages
+    (custom1 map, r = 2) at batch sizes where the library leaves the LDS simulator's fused mode: 10 qubits and
+    up, the register-resident kernel's own reduced-density-matrix mode (no workspace); 8 qubits (packed samples), simulate
+    + reduce through a workspace (qk_simulate_rdm1_wants_workspace).  What the library picks, the call without a workspace,
+    simulate + rdm1 done by hand and the oracle agree; small batches of the same circuit ask for no workspace."""
     import torch
     from quake_amd import _lib, device as qdev, featuremaps as fm
     from quake_amd.circuit import ParameterVector
+    from tests._helpers import psi_from_compiled
     lib = _lib.load()
     fmap = fm.custom1_featuremap(ParameterVector("x", n), n, 2)
     circ = qdev.DeviceCircuit(fmap)
     assert lib.qk_simulate_rdm1_is_fused(circ.handle.handle) == 1
-    assert lib.qk_simulate_rdm1_wants_workspace(circ.handle.handle, N) == 1
+    assert lib.qk_simulate_rdm1_wants_workspace(circ.handle.handle, N) == workspace
     assert lib.qk_simulate_rdm1_wants_workspace(circ.handle.handle, 64) == 0
     X = np.random.default_rng(60 + n).uniform(-1.0, 1.0, size=(N, circ.n_params))
     Xd = torch.from_numpy(X).cuda()
     got = qdev.simulate_rdm1(circ, Xd)
-    fused = torch.empty_like(got)
-    _lib.check(lib.qk_simulate_rdm1_dev(circ.handle.handle, Xd.data_ptr(), N, Xd.stride(0), fused.data_ptr(), None, None))
+    no_ws = torch.empty_like(got)
+    _lib.check(lib.qk_simulate_rdm1_dev(circ.handle.handle, Xd.data_ptr(), N, Xd.stride(0), no_ws.data_ptr(), None, None))
+    by_hand = qdev.rdm1(circ.simulate(Xd), n)
     torch.cuda.synchronize()
-    assert float((got - fused).abs().max()) < 1e-13
+    assert float((got - no_ws).abs().max()) < 1e-13 and float((got - by_hand).abs().max()) < 1e-13
     rows = np.unique(np.concatenate([[0, 1, N - 1], np.random.default_rng(n).integers(0, N, 5)]))
-    from tests._helpers import psi_from_compiled
     r = O.rdm1(psi_from_compiled(fmap, X[rows]), n)
     want = np.stack([r[..., 0, 0].real, r[..., 1, 1].real, r[..., 0, 1].real, r[..., 0, 1].imag], axis=-1)
     assert np.abs(got[torch.from_numpy(rows).cuda()].cpu().numpy() - want).max() < 1e-13
