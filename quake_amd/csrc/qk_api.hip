@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "qk_common.h"
+#include "qk_reg.h"
 
 namespace qk {
 
@@ -146,6 +147,12 @@ extern "C" int qk_circuit_create(int n_qubits, int n_params, const qk_op* ops, i
     }
     bool any_narrow = false;
     for (const Pass& ps : c->passes) any_narrow |= ps.narrow;
+    // ... and so does a circuit whose register-resident plan holds 8 amplitudes per thread: that kernel's reduced-density-
+    // matrix mode needs the 16-amplitude form (qk_reg.hip, reg_rdm_mode_ok)
+    if (!c->reg_blob.empty()) {
+        const RegHeader* H = (const RegHeader*)c->reg_blob.data();
+        any_narrow |= H->rb == 3 && H->nq == H->L;
+    }
     if (any_narrow) {      // the fused simulate + RDM mode runs its own plan of the same gates (see qk_circuit::rdm_plan)
         qk_circuit* r = new (std::nothrow) qk_circuit();
         if (!r) { delete c; return fail(QK_ERR_INVALID, "qk_circuit_create: out of memory"); }

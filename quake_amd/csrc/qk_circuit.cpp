@@ -676,7 +676,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             }
         }
         int RB = 4;
-        if (rb_env == 3 || rb_env == 4) RB = rb_env;
+        if (!allow_narrow && Lv == n) RB = 4;      // the plan of the reduced-density-matrix mode (qk_circuit::rdm_plan): its reduction needs the 16-amplitude form
+        else if (rb_env == 3 || rb_env == 4) RB = rb_env;
         else if (n <= 7) RB = 3;
         else if (2 * busy >= n) RB = (n_diag_terms >= 2 * n && draft(3).size() > draft(4).size()) ? 4 : 3;
         const int n_samp = 1 << (Lv - n);      // samples per workgroup

@@ -128,6 +128,34 @@ def test_simulate_rdm1_routes(n, N, workspace):
     assert np.abs(got[torch.from_numpy(rows).cuda()].cpu().numpy() - want).max() < 1e-13
 
 
+@pytest.mark.parametrize("n,seed,N", [(10, 3, 4096 + 7), (11, 20, 2048 + 3), (12, 21, 1024 + 5)])
+def test_simulate_rdm1_busy_circuit_uses_the_sixteen_amplitude_plan(n, seed, N):
+    """A circuit full of matrix butterflies and swaps simulates with 8 amplitudes per thread, but the register-resident
+    kernel's reduced-density-matrix mode needs 16: such circuits carry a second plan for that mode (qk_circuit::rdm_plan,
+    "rdm_plan yes").  Large batch: the library's route (no workspace asked), simulate + rdm1 by hand (the 8-amplitude
+    plan) and the oracle agree."""
+    import torch
+    from quake_amd import _lib, device as qdev
+    from tests._helpers import psi_from_compiled
+    from tests.test_gpu_parity import _gate_soup
+    lib = _lib.load()
+    c = _gate_soup(n, seed, 4 * n)
+    circ = qdev.DeviceCircuit(c)
+    s = circ.handle.plan_summary
+    assert "rdm_plan yes" in s and f"workgroup of {(1 << n) // 8} threads" in s, s
+    assert lib.qk_simulate_rdm1_wants_workspace(circ.handle.handle, N) == 0
+    X = np.random.default_rng(80 + n).uniform(-1.0, 1.0, size=(N, circ.n_params))
+    Xd = torch.from_numpy(X).cuda()
+    got = qdev.simulate_rdm1(circ, Xd)
+    by_hand = qdev.rdm1(circ.simulate(Xd), n)
+    torch.cuda.synchronize()
+    assert float((got - by_hand).abs().max()) < 1e-13
+    rows = np.unique(np.concatenate([[0, 1, N - 1], np.random.default_rng(n).integers(0, N, 5)]))
+    r = O.rdm1(psi_from_compiled(c, X[rows]), n)
+    want = np.stack([r[..., 0, 0].real, r[..., 1, 1].real, r[..., 0, 1].real, r[..., 0, 1].imag], axis=-1)
+    assert np.abs(got[torch.from_numpy(rows).cuda()].cpu().numpy() - want).max() < 1e-13
+
+
 def test_k_block_to_host_leg():
     """ShardedGram.compute(K_host=...): the row block also lands in page-locked host memory through
     qk_block_to_host_async on a side stream (strided 2-D copies, no temporaries)."""
