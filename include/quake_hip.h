@@ -190,8 +190,8 @@ int qk_rdm1_dev(const void* psi_dev, int64_t N, int n_qubits, double* rdm_dev, v
 /*
  * Replaces: the same two steps of projected_quantum_kernel (reference genetic_v3.py:795-803:
  * assign_parameters -> DensityMatrix -> partial_trace per qubit) without ever writing the
- * statevectors: when the circuit runs as one LDS-resident pass (qk_simulate_rdm1_is_fused: n <= 12
- * qubits, or 13 where the planner keeps 13 local), the reduced density matrices are reduced from LDS
+ * statevectors: when the circuit runs as one pass over a state that stays on the chip
+ * (qk_simulate_rdm1_is_fused: up to 13 qubits), the reduced density matrices are reduced from LDS
  * at the end of the simulation.  Otherwise psi_ws_dev (N x 2^n complex128 workspace) is required and
  * the call is qk_simulate_dev + qk_rdm1_dev.
  */

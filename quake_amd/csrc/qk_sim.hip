@@ -1276,7 +1276,9 @@ static bool shape_h_layers(const qk_circuit& c) {
 static bool reg_rdm_route(const qk_circuit& c, int64_t N) {
     static const int env = [] { const char* e = std::getenv("QK_RDM_REG"); return e ? std::atoi(e) : -1; }();      // (A/B runs: 0 never, 1 always)
     static const bool force_reg = [] { const char* e = std::getenv("QK_SIM_PATH"); return e && std::strcmp(e, "reg") == 0; }();
-    if (env == 0 || !reg_rdm_mode_ok(c) || c.passes.size() != 1) return false;
+    if (!reg_rdm_mode_ok(c) || c.passes.size() != 1) return false;
+    if (c.passes[0].L != c.n_qubits) return true;      // (the LDS kernel cannot run this circuit fused: 13 qubits with a chunk bit)
+    if (env == 0) return false;
     if (env == 1 || force_reg) return true;
     const int n = c.n_qubits;
     return (N << n) >= ((int64_t)1 << 22) && !(n == 10 && shape_h_layers(c));
@@ -1636,6 +1638,10 @@ extern "C" int qk_simulate_rdm1_dev(const qk_circuit* cc, const double* X_dev, i
 }
 
 extern "C" int qk_simulate_rdm1_is_fused(const qk_circuit* c) {
-    // the whole statevector of a sample is one LDS-resident chunk of a single pass
-    return c && c->passes.size() == 1 && c->passes[0].L == c->n_qubits && c->n_qubits <= qk::RDM_MAXQ ? 1 : 0;
+    if (!c) return 0;
+    // the whole statevector of a sample is one LDS-resident chunk of a single pass ...
+    if (c->passes.size() == 1 && c->passes[0].L == c->n_qubits && c->n_qubits <= qk::RDM_MAXQ) return 1;
+    // ... or the register-resident kernel holds it (13 qubits where the LDS plan keeps a chunk bit: GA genomes)
+    const qk_circuit& r = c->rdm_plan ? *c->rdm_plan : *c;
+    return r.passes.size() == 1 && qk::reg_rdm_mode_ok(r) ? 1 : 0;
 }
