@@ -609,6 +609,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     // and only the angles, matrices and phase tables exist once per sample.
     c.reg_blob.clear();
     bool q_tables = true;      // register-thread terms of diagonal stages as ratio tables (below)
+    static const bool merge_tables = !(std::getenv("QK_REG_MERGE") && std::atoi(std::getenv("QK_REG_MERGE")) == 0);      // (A/B runs)
     auto plan_reg = [&](const int Lv, const size_t lds_limit, size_t* dry_lds = nullptr) -> bool {      // dry_lds: only report the LDS a workgroup would need
         // Single-qubit gates on distinct qubits with nothing between them commute: inside such a run the gates are
         // taken in ascending qubit order, so that a layer of gates fills whole groups of four neighbouring qubits and
@@ -689,6 +690,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         }
         std::vector<RegSeg> segs;
         std::vector<RegOp> rops;
+        std::vector<int> diag_hs;          // per diagonal op, in order: slots of its high-bits table
         std::vector<RegTab> tabs;
         std::vector<RegTerm> rterms;      // terms the simulator evaluates per thread (between two thread bits, or a register and a thread bit)
         struct TabTerm { int type, va, vb, tag; };
@@ -891,9 +893,14 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                     // held in the running scale: the stage writes its phases instead of multiplying by them
                     if (!rops.empty() && (int)rops.size() == sg.op0 + 1 && rops.back().kind == RG_INIT && (rops.back().flags & 1)) op.flags |= 256;
                     op.tab = tables(tstart[0], tstart[1] - tstart[0], tstart[1], tstart[2] - tstart[1], tstart[2], tstart[3] - tstart[2]) - n_itab;
-                    if (op.flags & 512)      // the ratio tables of the register positions that have any, in order of position
+                    const int hs = hi.empty() ? 0 : 1 << std::max(0, (int)hi.size() - 4);      // slots of the high-bits table
+                    op.a = op.tab + 1;                 // Blo, Bhi: consecutive for now; equal tables are merged below
+                    op.b = op.tab + 2;
+                    op.tab |= (op.tab + 2 + hs) << 16; // the ratio tables of the register positions that have any, in order of position
+                    if (op.flags & 512)
                         for (int rp = 0; rp < RB; ++rp)
                             if ((op.flags >> rp) & 1) thread_tables(qstart[rp][0], qstart[rp][1] - qstart[rp][0], qstart[rp][1], qstart[rp][2] - qstart[rp][1]);
+                    diag_hs.push_back(hs);
                     op.t0 = start[3];
                     op.nTX = start[4] - start[3];
                     op.nRT = start[5] - start[4];
@@ -976,6 +983,56 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
                 tts.push_back(r);
             }
             tb.t0 = first;
+        }
+        // Equal tables exist once: the repetitions of a map apply the same diagonal stage in different layouts, and what was
+        // the register table of one is a thread table of the other (ZZ r = 2 at 8 qubits: four stage tables per sample
+        // become two -- a third less for the table kernel to write, for the simulator to fetch and to hold in LDS).
+        // A table = its bits' count and its (angle, masks) records; high-bits tables compare slot group by slot group.
+        if (merge_tables) {
+            auto same = [&](int x, int y, int count) {
+                for (int k = 0; k < count; ++k) {
+                    const RegTab &tx = tabs[n_itab + x + k], &ty = tabs[n_itab + y + k];
+                    if (tx.nbits != ty.nbits || tx.nt != ty.nt) return false;
+                    for (int t = 0; t < tx.nt; ++t)
+                        if (tts[tx.t0 + t].expr != tts[ty.t0 + t].expr || tts[tx.t0 + t].masks != tts[ty.t0 + t].masks) return false;
+                }
+                return true;
+            };
+            const int n_d = (int)tabs.size() - n_itab;
+            std::vector<int> keep(n_d, 1), target(n_d, -1);      // target: the earlier table a dropped one is replaced by
+            struct Group { int first, count; };
+            std::vector<Group> groups;      // the A / Blo / Bhi groups seen so far (ratio tables are left alone)
+            int di = 0;
+            for (RegOp& o : rops) {
+                if (o.kind != RG_DIAG) continue;
+                const int hs = diag_hs[di++];
+                int* idx[3] = {nullptr, &o.a, &o.b};
+                const int first[3] = {o.tab & 0xffff, o.a, o.b}, count[3] = {1, 1, hs};
+                for (int k = 0; k < 3; ++k) {
+                    if (count[k] == 0) continue;
+                    int hit = -1;
+                    for (const Group& g : groups)
+                        if (g.count == count[k] && same(g.first, first[k], count[k])) { hit = g.first; break; }
+                    if (hit < 0) { groups.push_back(Group{first[k], count[k]}); continue; }
+                    for (int j = 0; j < count[k]; ++j) { keep[first[k] + j] = 0; target[first[k] + j] = hit + j; }
+                    if (k == 0) o.tab = (o.tab & ~0xffff) | hit; else *idx[k] = hit;
+                }
+            }
+            std::vector<int> remap(n_d + 1, 0);
+            int n_new = 0;
+            for (int t = 0; t < n_d; ++t) { remap[t] = n_new; n_new += keep[t]; }
+            remap[n_d] = n_new;
+            auto moved = [&](int t) { return t < n_d && !keep[t] ? remap[target[t]] : remap[t]; };
+            for (RegOp& o : rops) {
+                if (o.kind != RG_DIAG) continue;
+                o.tab = moved(o.tab & 0xffff) | (remap[(o.tab >> 16) & 0xffff] << 16);
+                o.a = moved(o.a);
+                o.b = moved(o.b);
+            }
+            std::vector<RegTab> kept(tabs.begin(), tabs.begin() + n_itab);
+            for (int t = 0; t < n_d; ++t)
+                if (keep[t]) kept.push_back(tabs[n_itab + t]);
+            tabs.swap(kept);
         }
         const bool fits = (int)tabs.size() <= kRegMaxTabs && (int)rterms.size() <= kRegMaxTerms && (int)rmats.size() <= std::min(kRegMaxMats, 255);
         // LDS: the transpose image; per sample the product-state tables (unless all-Hadamard);

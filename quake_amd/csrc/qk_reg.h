@@ -36,8 +36,9 @@ enum RegOpKind : int32_t {
 struct RegOp {        // 32 bytes
     int32_t kind;
     int32_t a, b;
-    int32_t tab;      // INIT / DIAG: first table: A, Blo, Bhi (two slots when the thread has nine bits; none when it has at most
-                      // four); DIAG: counted from RegHeader::n_itab
+    int32_t tab;      // INIT: first table: A, Blo, Bhi (two slots when the thread has nine bits; none when it has at most four).
+                      // DIAG, counted from RegHeader::n_itab: bits 0..15 table A, a = Blo, b = Bhi (first slot), bits 16..31 the
+                      // first ratio table (flags bit 9) -- equal tables of different stages exist once
     int32_t t0;       // DIAG: first of the terms evaluated per thread (RegTerm): nTX between two thread bits, then nRT between a
     int32_t nTX, nRT; //       register bit and a thread bit (bits 8.. of RegTerm::type = that register position)
     int32_t flags;    // DIAG: bits 0..3 = register positions that have RT terms, bit 8 = the state is still the identity; INIT: bit 0 = every first gate is a Hadamard;

@@ -560,8 +560,11 @@ hadamard_pos<0, NA>(v);
                         }
                     }
                 } else if (kind == RG_DIAG || kind == RG_INIT) {
-                    const int tb0 = o_tab;
-                    const uint32_t ta = (kind == RG_INIT ? itab_l : dtab_l) + 256u * (uint32_t)tb0;      // table A: the register bits
+                    // table A (the register bits), then the tables of the low and of the high thread bits: consecutive for the
+                    // product state; a diagonal stage names each of them (stages that repeat share their tables)
+                    const uint32_t ta = (kind == RG_INIT ? itab_l : dtab_l) + 256u * ((uint32_t)o_tab & 0xffffu);
+                    const uint32_t tl = kind == RG_INIT ? ta + 256u : dtab_l + 256u * (uint32_t)oa;
+                    const uint32_t th = kind == RG_INIT ? ta + 512u : dtab_l + 256u * (uint32_t)ob;
                     // the sixteen entries of the register table: on their way before anything else of the stage, so that the
                     // waits below (thread tables, terms) cover them as well
                     v2d ph[NA];
@@ -574,11 +577,11 @@ hadamard_pos<0, NA>(v);
                     }
                     v2d bt;
                     if constexpr (PACK) {      // the thread's bits above the circuit's qubits number the sample: not part of the table index
-                        bt = ldsr<v2d>(ta + 256u + 16u * ((uint32_t)tid & ((1u << n_lo) - 1u)));
-                        if (n_hi > 0) bt = cmul(bt, ldsr<v2d>(ta + 512u + 16u * (((uint32_t)tid >> 4) & ((1u << n_hi) - 1u))));
+                        bt = ldsr<v2d>(tl + 16u * ((uint32_t)tid & ((1u << n_lo) - 1u)));
+                        if (n_hi > 0) bt = cmul(bt, ldsr<v2d>(th + 16u * (((uint32_t)tid >> 4) & ((1u << n_hi) - 1u))));
                     } else {
                         const uint32_t tlo = (uint32_t)tid & 15u, thi = (uint32_t)tid >> 4;
-                        bt = cmul(ldsr<v2d>(ta + 256u + 16u * tlo), ldsr<v2d>(ta + 512u + 16u * thi));   // (thi >= 16: the second Bhi slot follows the first)
+                        bt = cmul(ldsr<v2d>(tl + 16u * tlo), ldsr<v2d>(th + 16u * thi));   // (thi >= 16: the second Bhi slot follows the first)
                     }
                     if (kind == RG_INIT) {
                         const int all_h = o_flags & 1;
@@ -622,7 +625,7 @@ hadamard_pos<0, NA>(v);
                             // what flipping that bit multiplies the phase by, as a product of a table over the low and one
                             // over the high thread bits (behind the stage's own three tables, in order of position).
                             const uint32_t hs = n_hi > 4 ? 1u << (n_hi - 4) : (n_hi > 0 ? 1u : 0u);      // slots of the high-bits table
-                            uint32_t qa = ta + 256u * (2u + hs);
+                            uint32_t qa = dtab_l + 256u * ((uint32_t)o_tab >> 16);
                             auto ratio = [&](uint32_t at) __attribute__((always_inline)) {
                                 if constexpr (PACK) {
                                     v2d q = ldsr<v2d>(at + 16u * ((uint32_t)tid & ((1u << n_lo) - 1u)));

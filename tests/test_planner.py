@@ -116,7 +116,7 @@ def test_packed_register_plans_below_ten_qubits():
     assert plan_of(zz(8, 2))[0] == 2 and plan_of(zz(9, 2))[0] == 3           # segments of four register qubits
     assert plan_of(zz(12, 2))[3:] == (1, 256) and plan_of(zz(10, 2))[3:] == (1, 64)
     assert plan_of(_gate_soup(4, 30, 36)) is None      # 64 samples' tables and matrices next to each other: no room
-    assert plan_of(_gate_soup(6, 32, 54))[3:] == (16, 128)      # 8 amplitudes per thread: 16 samples, not 64, share a workgroup
+    assert plan_of(_gate_soup(6, 32, 54))[3:] == (32, 256)      # 8 amplitudes per thread: 32 samples, not 64, share a workgroup
     assert plan_of(_gate_soup(8, 34, 72)) is not None and plan_of(_gate_soup(13, 22, 117)) is not None
     assert plan_of(zz(3, 1)) is None and plan_of(zz(14, 2)) is None          # below 4 qubits / two passes
 
@@ -160,7 +160,9 @@ def test_register_plan_ratio_tables_need_many_register_thread_terms():
     x12 = ParameterVector("x", 12)
     full = _reg_plan(fm.zz_featuremap(x12, 12, 2, entanglement="full"))
     lin = _reg_plan(zz(12, 2))
-    assert lin["ratio_positions"] == 0 and lin["tables"] == 9           # INIT + two stages of (A, Blo, Bhi)
+    assert lin["ratio_positions"] == 0 and lin["tables"] == 6           # INIT's (A, Blo, Bhi) + ONE set for both stages: the
+    # second stage's tables are the first one's in another order (its register qubits were thread qubits there)
+    assert _reg_plan(zz(12, 3))["tables"] == 6 and _reg_plan(zz(8, 2))["tables"] == 4
     assert full["ratio_positions"] == 8 and full["tables"] == 9 + 2 * 8
     x13 = ParameterVector("x", 13)
     full13 = _reg_plan(fm.zz_featuremap(x13, 13, 2, entanglement="full"))
