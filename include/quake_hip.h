@@ -114,9 +114,13 @@ int qk_circuit_num_passes(const qk_circuit* c);
  * reference qsvm/train.py:92,152,154, genetic_v3.py:618-619).
  *   X    : N x n_params float64, row stride ldx (elements)
  *   psi  : N x 2^n complex128, written
- * Circuits of more than 10 qubits take a temporary table (16 bytes per sample and gate angle) from the
- * device's default memory pool in stream order (hipMallocAsync / hipFreeAsync on `stream`): nothing outlives
- * the call's work, no synchronisation.
+ * Temporary tables (the gate angles' cosines and sines, the phase tables of diagonal stages: up to 1 GiB, twice
+ * that when they alternate) come from the device's default memory pool in stream order (hipMallocAsync /
+ * hipFreeAsync on `stream`): nothing outlives the call's work, no synchronisation.  Large calls on narrow
+ * registers (2^25 amplitudes or more, tables of 3/8 of Psi or more: DESIGN.md 4.2r) also launch their table
+ * kernels on a stream the library owns (one per GPU, created on the first such call), joined to `stream` by
+ * events on both sides: everything the call enqueues is still ordered behind what `stream` held before the
+ * call, and whatever the caller enqueues on `stream` afterwards is ordered behind all of the call's work.
  */
 int qk_simulate_dev(const qk_circuit* c, const double* X_dev, int64_t N, int64_t ldx,
                     void* psi_dev, void* stream);

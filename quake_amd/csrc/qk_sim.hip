@@ -1369,38 +1369,116 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
     if (dt.reg && reg_mode >= 0 && (rdm_dev ? reg_rdm : (reg_mode > 0 || reg_pays))) {
         const RegHeader* H = (const RegHeader*)c.reg_blob.data();
         // The angles and the stage tables of the batch live in stream order.  Large batches go in chunks of whole sample
-        // groups so that those tables stay within 1 GiB whatever N is.
+        // groups: the tables stay within 1 GiB whatever N is, and the pre-pass kernels of chunk k + 1 (a seventh of the time
+        // of a call: tools/sim_bench.py under rocprofv3) run on a side stream while the simulator works on chunk k -- the
+        // simulator leaves a third of a SIMD's registers and most of its wave slots free, the pre-pass kernels use no LDS.
         const int64_t per_sample = (int64_t)H->n_expr * 16 + (int64_t)(H->n_tab - H->n_itab) * 256 + (int64_t)H->n_mat * 64;
         const int64_t group = (int64_t)1 << (H->L - H->nq);
         int64_t chunk = per_sample > 0 ? std::max<int64_t>(((int64_t)1 << 30) / per_sample, 65536) : N;
-        chunk = std::min<int64_t>(N, chunk / group * group);
-        for (int64_t s0 = 0; s0 < N; s0 += chunk) {
-            const int64_t Nc = std::min(chunk, N - s0);
-            double2* cs = nullptr;
-            void* tabs = nullptr;
-            if (H->n_expr > 0) {
-                if ((Nc + 63) / 64 > 0x7fffffff) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
-                if ((rc = scratch_alloc((void**)&cs, (size_t)H->n_expr * (size_t)Nc * sizeof(double2), (hipStream_t)stream))) return rc;
-                hipLaunchKernelGGL(angle_table_kernel, dim3((unsigned)((Nc + 63) / 64), (unsigned)((H->n_expr + 3) / 4)), dim3(256), 0,
-                                   (hipStream_t)stream, (const DevExpr*)((const char*)dt.reg + H->off_expr), H->n_expr, dt.prog, dt.consts,
-                                   X_dev + s0 * ldx, ldx, Nc, cs);
+        static const int overlap_env = [] { const char* e = std::getenv("QK_REG_OVERLAP"); return e ? std::atoi(e) : -1; }();      // (A/B runs: 0 off, k >= 2 chunks)
+        // Four chunks, from 2^25 amplitudes (a call of half a millisecond), where a sample's tables are three eighths of its
+        // statevector or more -- that is, narrow registers or many parametrised gates (measured at 4 GiB of Psi, one chunk ->
+        // four: 4 qubits ZZ r = 2 12.6 -> 11.7 ms, genome 17.0 -> 13.0; 5 qubits custom1 19.5 -> 17.2; 6 qubits genome
+        // 9.7 -> 8.0; 7 qubits custom1 5.9 -> 4.9; 8 qubits custom1 3.9 -> 3.4).  Below that share the four launches' tails
+        // and the kernels sharing the CUs cost more than the pre-pass was (8 qubits ZZ r = 2, 0.19 of Psi: 1.66 -> 1.79; 12
+        // qubits genome, 0.04: 1.73 -> 2.0 and more).
+        int parts = 1;
+        if (overlap_env >= 2) parts = overlap_env;
+        else if (overlap_env != 0 && per_sample * 8 >= 3 * ((int64_t)16 << n) && (N << n) >= ((int64_t)1 << 25)) parts = 4;
+        if (parts > 1) chunk = std::min(chunk, (N + parts - 1) / parts);
+        chunk = std::max<int64_t>(group, std::min<int64_t>(N, chunk / group * group));
+        const bool overlap = parts > 1 && chunk < N;
+        static const bool dbg_reg = std::getenv("QK_REG_DEBUG") != nullptr;
+        if (dbg_reg) std::fprintf(stderr, "reg call: n %d N %lld table bytes per sample %lld (%.2f of Psi) chunk %lld parts %d\n", n, (long long)N,
+                                  (long long)per_sample, (double)per_sample / (double)((int64_t)16 << n), (long long)chunk, overlap ? parts : 1);
+        hipStream_t side = nullptr;
+        // events: a ring per device, created once and never destroyed (an event handed to hipStreamWaitEvent and destroyed
+        // right away lost the wait now and then on this runtime: a chunk's simulator then read tables not yet written)
+        constexpr int kEvents = 64;
+        static std::mutex ev_mu;
+        static hipStream_t side_streams_[64] = {};
+        static hipEvent_t ev_ring[64][kEvents] = {};
+        static unsigned ev_next[64] = {};
+        int dev = 0;
+        auto next_event = [&](hipEvent_t* out) -> int {
+            std::lock_guard<std::mutex> lock(ev_mu);
+            hipEvent_t& e = ev_ring[dev][ev_next[dev]++ % kEvents];
+            if (!e) QK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            *out = e;
+            return QK_OK;
+        };
+        if (overlap) {
+            QK_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64) return fail(QK_ERR_UNSUPPORTED, "device index out of range");
+            {
+                std::lock_guard<std::mutex> lock(ev_mu);
+                if (!side_streams_[dev]) QK_HIP(hipStreamCreateWithFlags(&side_streams_[dev], hipStreamNonBlocking));
+                side = side_streams_[dev];
             }
-            const size_t tb = reg_side_bytes(c, Nc);
+        }
+        const hipStream_t main_s = (hipStream_t)stream;
+        const hipStream_t pre = overlap ? side : main_s;
+        // The buffers of a call -- one set, or two that alternate when the pre-pass runs ahead -- are allocated and freed in the
+        // caller's stream order only: the side stream launches kernels and nothing else (memory that one stream frees and the
+        // other allocates while the free is still pending came back before its last reader had finished).
+        const int nbuf = overlap ? 2 : 1;
+        double2* cs_buf[2] = {nullptr, nullptr};
+        void* tab_buf[2] = {nullptr, nullptr};
+        hipEvent_t sim_done[2] = {nullptr, nullptr};
+        const size_t tb_max = reg_side_bytes(c, chunk);
+        if (H->n_expr > 0 && (chunk + 63) / 64 > 0x7fffffff) return fail(QK_ERR_UNSUPPORTED, "qk_simulate_dev: N too large");
+        auto release = [&](int code) {
+            if (code != QK_OK && overlap) (void)hipStreamSynchronize(side);      // (kernels of the side stream may still be writing)
+            for (int b = 0; b < nbuf; ++b) {
+                if (cs_buf[b]) (void)hipFreeAsync(cs_buf[b], main_s);
+                if (tab_buf[b]) (void)hipFreeAsync(tab_buf[b], main_s);
+            }
+            return code;
+        };
+        for (int b = 0; b < nbuf; ++b) {
+            if (H->n_expr > 0 && (rc = scratch_alloc((void**)&cs_buf[b], (size_t)H->n_expr * (size_t)chunk * sizeof(double2), main_s))) return release(rc);
+            if (tb_max > 0 && (rc = scratch_alloc(&tab_buf[b], tb_max, main_s))) return release(rc);
+        }
+        if (overlap) {
+            // the side stream starts where the caller's stream is now (X is ready there, the buffers are allocated)
+            hipEvent_t ev_in = nullptr;
+            if ((rc = next_event(&ev_in))) return release(rc);
+            if (hipEventRecord(ev_in, main_s) != hipSuccess || hipStreamWaitEvent(side, ev_in, 0) != hipSuccess)
+                return release(fail(QK_ERR_HIP, "qk_simulate_dev: event between the caller's stream and the pre-pass stream"));
+        }
+        int64_t k = 0;
+        for (int64_t s0 = 0; s0 < N; s0 += chunk, ++k) {
+            const int64_t Nc = std::min(chunk, N - s0);
+            const int b = (int)(k % nbuf);
+            double2* cs = cs_buf[b];
+            void* tabs = tab_buf[b];
+            // (this set's previous reader, the simulator of chunk k - 2, has to be done before the pre-pass writes it again)
+            if (overlap && sim_done[b] && hipStreamWaitEvent(side, sim_done[b], 0) != hipSuccess)
+                return release(fail(QK_ERR_HIP, "qk_simulate_dev: hipStreamWaitEvent"));
+            if (H->n_expr > 0)
+                hipLaunchKernelGGL(angle_table_kernel, dim3((unsigned)((Nc + 63) / 64), (unsigned)((H->n_expr + 3) / 4)), dim3(256), 0,
+                                   pre, (const DevExpr*)((const char*)dt.reg + H->off_expr), H->n_expr, dt.prog, dt.consts,
+                                   X_dev + s0 * ldx, ldx, Nc, cs);
             rc = QK_OK;
-            if (tb > 0) {
-                rc = scratch_alloc(&tabs, tb, (hipStream_t)stream);
-                if (rc == QK_OK) rc = launch_reg_side(c, dt.reg, cs, Nc, tabs, (hipStream_t)stream);
+            if (tb_max > 0) rc = launch_reg_side(c, dt.reg, cs, Nc, tabs, pre);
+            if (rc == QK_OK && overlap) {      // the simulator's launch waits for this chunk's pre-pass
+                hipEvent_t ev = nullptr;
+                if ((rc = next_event(&ev))) return release(rc);
+                if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent(main_s, ev, 0) != hipSuccess)
+                    return release(fail(QK_ERR_HIP, "qk_simulate_dev: event between the pre-pass stream and the caller's stream"));
             }
             if (rc == QK_OK && rdm_dev)
-                rc = launch_reg_sim(c, dt.reg, cs, tabs, Nc, nullptr, nullptr, (hipStream_t)stream, rdm_dev + s0 * (int64_t)(4 * n));
+                rc = launch_reg_sim(c, dt.reg, cs, tabs, Nc, nullptr, nullptr, main_s, rdm_dev + s0 * (int64_t)(4 * n));
             else if (rc == QK_OK)
                 rc = launch_reg_sim(c, dt.reg, cs, tabs, Nc, psi32_dev ? nullptr : (void*)((double2*)psi_dev + (s0 << n)),
-                                    psi32_dev ? (void*)((float2*)psi32_dev + (s0 << n)) : nullptr, (hipStream_t)stream);
-            if (cs) (void)hipFreeAsync(cs, (hipStream_t)stream);
-            if (tabs) (void)hipFreeAsync(tabs, (hipStream_t)stream);
-            if (rc != QK_OK) return rc;
+                                    psi32_dev ? (void*)((float2*)psi32_dev + (s0 << n)) : nullptr, main_s);
+            if (rc != QK_OK) return release(rc);
+            if (overlap && s0 + 2 * chunk < N) {      // (only when a later chunk will write this set again)
+                if ((rc = next_event(&sim_done[b]))) return release(rc);
+                if (hipEventRecord(sim_done[b], main_s) != hipSuccess) return release(fail(QK_ERR_HIP, "qk_simulate_dev: hipEventRecord"));
+            }
         }
-        return QK_OK;
+        return release(QK_OK);
     }
     if (dt.wave && !rdm_dev && !force_lds && !prefer_lds) {
         WaveJob job{};

@@ -324,11 +324,46 @@ def test_register_resident_simulator_in_chunks():
     assert "register-resident plan" in HipFidelityKernel(circ)._circuit().plan_summary
     X = synth_X(N, n, "scaled", 77)
     psi = qdev.DeviceCircuit(circ).simulate(torch.from_numpy(X).cuda())
-    rows = np.unique(np.concatenate([[0, 1, N - 2, N - 1], np.arange(780200, 780400), np.random.default_rng(5).integers(0, N, 200)]))
+    # (the seams: one chunk of 2^30 / 1376 samples and the rest -- or, when the pre-pass runs ahead on its own stream, see
+    # the next test, four chunks of a quarter of the batch rounded down to whole groups)
+    seams = [np.arange(780200, 780400)] + [np.arange(k * N // 4 - 300, k * N // 4 + 50) for k in (1, 2, 3)]
+    rows = np.unique(np.concatenate([[0, 1, N - 2, N - 1], *seams, np.random.default_rng(5).integers(0, N, 200)]))
     got = psi[torch.from_numpy(rows).cuda()].cpu().numpy()
     assert np.abs(got - O.statevectors(oops, n, X[rows])).max() < TOL_PSI
     assert float(((psi.real ** 2 + psi.imag ** 2).sum(dim=1) - 1.0).abs().max()) < 1e-12
     del psi
+
+
+def test_register_resident_prepass_runs_ahead():
+    """Where a sample's angle and stage tables are three eighths of its statevector or more (5 qubits, custom1 map r = 2:
+    3.75 times), a call of 2^25 amplitudes or more goes in four chunks and the pre-pass kernels of chunk k + 1 run on the
+    library's side stream while the simulator works on chunk k, two sets of tables alternating (qk_sim.hip, the register
+    branch of simulate_impl).  Two calls back to back on a stream that is not the default one, no synchronisation between
+    them -- the second call's pre-pass must not write a set that the first call's simulator is still reading -- then a
+    call on the default stream; rows around every seam against the oracle, every row's norm."""
+    import torch
+    from quake_amd import device as qdev, featuremaps as fm
+    n, N = 5, 1200003
+    fmap = fm.custom1_featuremap(qc.ParameterVector("x", n), n, 2)
+    dc = qdev.DeviceCircuit(fmap)
+    assert "register-resident plan" in dc.handle.plan_summary
+    Xs = [synth_X(N, n, "scaled", 900 + k) for k in range(2)]
+    Xd = [torch.from_numpy(x).cuda() for x in Xs]
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out = [dc.simulate(xd) for xd in Xd]
+    s.synchronize()
+    out.append(dc.simulate(Xd[0]))
+    torch.cuda.synchronize()
+    seams = [np.arange(k * N // 4 - 300, k * N // 4 + 50) for k in (1, 2, 3)]
+    rows = np.unique(np.concatenate([[0, 1, N - 2, N - 1], *seams, np.random.default_rng(6).integers(0, N, 100)]))
+    ridx = torch.from_numpy(rows).cuda()
+    for k, psi in enumerate(out):
+        assert np.abs(psi[ridx].cpu().numpy() - psi_from_compiled(fmap, Xs[k % 2][rows])).max() < TOL_PSI, k
+        assert float(((psi.real ** 2 + psi.imag ** 2).sum(dim=1) - 1.0).abs().max()) < 1e-12, k
+    assert torch.equal(out[0], out[2])
+    del out
 
 
 @pytest.mark.parametrize("n,seed", [(1, 0), (3, 1), (7, 2), (10, 3), (11, 4), (12, 5), (14, 6)])
