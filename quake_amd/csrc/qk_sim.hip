@@ -1385,6 +1385,11 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         int parts = 1;
         if (overlap_env >= 2) parts = overlap_env;
         else if (overlap_env != 0 && per_sample * 8 >= 3 * ((int64_t)16 << n) && (N << n) >= ((int64_t)1 << 25)) parts = 4;
+        if (parts > 1) {      // (not under stream capture: the side stream is made on first use, and a captured call stays on one stream)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); parts = 1; }
+            else if (cap != hipStreamCaptureStatusNone) parts = 1;
+        }
         if (parts > 1) chunk = std::min(chunk, (N + parts - 1) / parts);
         chunk = std::max<int64_t>(group, std::min<int64_t>(N, chunk / group * group));
         const bool overlap = parts > 1 && chunk < N;
@@ -1392,16 +1397,18 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
         if (dbg_reg) std::fprintf(stderr, "reg call: n %d N %lld table bytes per sample %lld (%.2f of Psi) chunk %lld parts %d\n", n, (long long)N,
                                   (long long)per_sample, (double)per_sample / (double)((int64_t)16 << n), (long long)chunk, overlap ? parts : 1);
         hipStream_t side = nullptr;
-        // events: a ring per device, created once and never destroyed (an event handed to hipStreamWaitEvent and destroyed
-        // right away lost the wait now and then on this runtime: a chunk's simulator then read tables not yet written)
-        constexpr int kEvents = 64;
-        static std::mutex ev_mu;
+        // Events: a ring per calling thread and device, created on first use and never destroyed (an event handed to
+        // hipStreamWaitEvent and destroyed right away is one of the two things the first form of this code did before it lost
+        // a wait now and then; a thread's calls come one after the other, a call waits for an event at most two chunks after
+        // recording it, so no record can overtake a wait that is still to be enqueued; the few events of a thread that ends
+        // stay with the process).
+        constexpr int kEvents = 16;
+        static std::mutex side_mu;
         static hipStream_t side_streams_[64] = {};
-        static hipEvent_t ev_ring[64][kEvents] = {};
-        static unsigned ev_next[64] = {};
+        thread_local hipEvent_t ev_ring[64][kEvents] = {};
+        thread_local unsigned ev_next[64] = {};
         int dev = 0;
         auto next_event = [&](hipEvent_t* out) -> int {
-            std::lock_guard<std::mutex> lock(ev_mu);
             hipEvent_t& e = ev_ring[dev][ev_next[dev]++ % kEvents];
             if (!e) QK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             *out = e;
@@ -1411,7 +1418,7 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
             QK_HIP(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64) return fail(QK_ERR_UNSUPPORTED, "device index out of range");
             {
-                std::lock_guard<std::mutex> lock(ev_mu);
+                std::lock_guard<std::mutex> lock(side_mu);
                 if (!side_streams_[dev]) QK_HIP(hipStreamCreateWithFlags(&side_streams_[dev], hipStreamNonBlocking));
                 side = side_streams_[dev];
             }

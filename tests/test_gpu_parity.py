@@ -366,6 +366,41 @@ def test_register_resident_prepass_runs_ahead():
     del out
 
 
+def test_register_resident_prepass_runs_ahead_two_threads():
+    """Two host threads, each with its own stream, call the simulator at the same time on batches that take the side
+    stream (the calls share the library's one side stream per GPU; events are per thread): both results equal the
+    single-threaded ones bit for bit."""
+    import threading
+    import torch
+    from quake_amd import device as qdev, featuremaps as fm
+    n, N = 5, 1100000
+    dcs = [qdev.DeviceCircuit(fm.custom1_featuremap(qc.ParameterVector("x", n), n, 2)),
+           qdev.DeviceCircuit(fm.zz_featuremap(qc.ParameterVector("x", n), n, 2))]
+    Xd = [torch.from_numpy(synth_X(N, n, "scaled", 950 + k)).cuda() for k in range(2)]
+    want = [dc.simulate(xd) for dc, xd in zip(dcs, Xd)]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    got[k] = dcs[k].simulate(Xd[k])
+            s.synchronize()
+        except Exception as e:      # noqa: BLE001 (reported below, in the main thread)
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(got[k], want[k]), k
+    del got, want
+
+
 @pytest.mark.parametrize("n,seed", [(1, 0), (3, 1), (7, 2), (10, 3), (11, 4), (12, 5), (14, 6)])
 def test_statevectors_single_qubit_runs(n, seed):
     """Long runs of single-qubit gates on one qubit between rare two-qubit gates (the shape of a GA genome
