@@ -1366,7 +1366,12 @@ static int simulate_impl(const qk_circuit* cc, const double* X_dev, int64_t N, i
                            ((direct_shape && all_h_init(c.passes[0])) || (h_layers_shape() && single_qubit_terms_only()));
     const bool reg_pays = n >= 11 ? !direct_shape : (!lds_at_10 && ((N >> reg_from) != 0 || (N << n) >= ((int64_t)1 << reg_from)));
     const bool reg_rdm = rdm_dev && dt.reg && reg_rdm_route(c, N);      // (its reduced-density-matrix mode: see reg_rdm_route)
-    if (dt.reg && reg_mode >= 0 && (rdm_dev ? reg_rdm : (reg_mode > 0 || reg_pays))) {
+    // (a reduced-density-matrix call on a circuit whose LDS plan keeps a chunk bit has no other fused route: QK_SIM_PATH does
+    // not apply to it)
+    const bool reg_rdm_only = reg_rdm && c.passes.size() == 1 && c.passes[0].L != n;
+    if (rdm_dev && !reg_rdm && !(c.passes.size() == 1 && c.passes[0].L == n && n <= RDM_MAXQ))
+        return fail(QK_ERR_UNSUPPORTED, "qk_simulate_rdm1_dev: no fused route for this circuit (a workspace is needed)");
+    if (dt.reg && (reg_mode >= 0 || reg_rdm_only) && (rdm_dev ? reg_rdm : (reg_mode > 0 || reg_pays))) {
         const RegHeader* H = (const RegHeader*)c.reg_blob.data();
         // The angles and the stage tables of the batch live in stream order.  Large batches go in chunks of whole sample
         // groups: the tables stay within 1 GiB whatever N is, and the pre-pass kernels of chunk k + 1 (a seventh of the time
