@@ -22,6 +22,7 @@ gate angle, evaluated on the device from the raw feature row.
 from __future__ import annotations
 
 import math
+import struct
 from dataclasses import dataclass
 from typing import Iterable, List, Optional, Sequence, Tuple, Union
 
@@ -155,24 +156,37 @@ class ParameterExpression:
             return l / r
         raise ValueError(op)
 
-    def postfix(self, column_of: dict, consts: list) -> List[Tuple[int, int]]:
-        """Postfix program ``[(opcode, arg), ...]``; constants are interned in ``consts``."""
-        op, a = self.op, self.args
-        if op == "const":
-            v = a[0]
-            for i, c in enumerate(consts):
-                # bit-exact interning (keeps -0.0 and 0.0 apart)
-                if np.float64(c).tobytes() == np.float64(v).tobytes():
-                    return [(EX_CONST, i)]
-            consts.append(v)
-            return [(EX_CONST, len(consts) - 1)]
-        if op == "param":
-            return [(EX_PARAM, column_of[self])]
-        un = {"neg": EX_NEG, "asin": EX_ASIN, "acos": EX_ACOS, "sin": EX_SIN, "cos": EX_COS}
-        if op in un:
-            return a[0].postfix(column_of, consts) + [(un[op], 0)]
-        bi = {"add": EX_ADD, "sub": EX_SUB, "mul": EX_MUL, "div": EX_DIV}
-        return a[0].postfix(column_of, consts) + a[1].postfix(column_of, consts) + [(bi[op], 0)]
+    _UNARY = {"neg": EX_NEG, "asin": EX_ASIN, "acos": EX_ACOS, "sin": EX_SIN, "cos": EX_COS}
+    _BINARY = {"add": EX_ADD, "sub": EX_SUB, "mul": EX_MUL, "div": EX_DIV}
+
+    def postfix(self, column_of: dict, consts: list, const_index: Optional[dict] = None,
+                out: Optional[list] = None) -> List[Tuple[int, int]]:
+        """Postfix program ``[(opcode, arg), ...]`` (appended to ``out`` when given); constants are interned in
+        ``consts`` by their bits (keeps -0.0 and 0.0 apart), ``const_index`` maps those bits to the position."""
+        if const_index is None:
+            const_index = {struct.pack("<d", c): i for i, c in enumerate(consts)}
+        prog = [] if out is None else out
+        # depth-first, operands before their operator, without recursion: (node, operands already emitted?)
+        todo = [(self, False)]
+        while todo:
+            e, done = todo.pop()
+            op = e.op
+            if op == "const":
+                key = struct.pack("<d", e.args[0])
+                i = const_index.get(key)
+                if i is None:
+                    i = const_index[key] = len(consts)
+                    consts.append(e.args[0])
+                prog.append((EX_CONST, i))
+            elif op == "param":
+                prog.append((EX_PARAM, column_of[e]))
+            elif done:
+                prog.append((self._UNARY[op] if len(e.args) == 1 else self._BINARY[op], 0))
+            else:
+                todo.append((e, True))
+                for a in reversed(e.args):
+                    todo.append((a, False))
+        return prog
 
     def stack_depth(self) -> int:
         if self.op in ("const", "param"):
@@ -408,13 +422,14 @@ class QuantumCircuit:
         params = self.parameters
         column_of = {p: k for k, p in enumerate(params)}
         consts: list = []
+        const_index: dict = {}
         ops, prog, off = [], [], [0]
         for ins in self.data:
             expr = -1
             if ins.angle is not None:
                 if ins.angle.stack_depth() > MAX_EXPR_STACK:
                     raise ValueError("gate-angle expression is nested too deeply for the device evaluator")
-                prog.extend(ins.angle.postfix(column_of, consts))
+                ins.angle.postfix(column_of, consts, const_index, prog)
                 off.append(len(prog))
                 expr = len(off) - 2
             q0 = ins.qubits[0]
