@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(256) reg_table_kernel(const char* blob, const 
     const int n_itab = hw[24];
     const int table = blockIdx.y;
     const int64_t sample = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (sample >= n_pad) return;
+    if (sample - (threadIdx.x & 63) >= n_pad) return;      // (whole waves only: every lane of a wave carries entries out below)
     const int64_t src = sample < N ? sample : N - 1;
     const CWords rec = cwords(blob + hw[12] + 32 * (n_itab + table));
     const int t0 = rec[6], nt = rec[7];
@@ -805,51 +805,130 @@ __global__ void __launch_bounds__(256) reg_table_kernel(const char* blob, const 
         for (int x = 0; x < 16; ++x)
             if ((masks >> x) & 1u) f[x] = cmul(f[x], ((masks >> (16 + x)) & 1u) ? uc : u);      // wave-uniform tests
     }
-    const int64_t s_in = sample & (((int64_t)1 << sh.sb) - 1);
-    v2d* o = (v2d*)out + (sample >> sh.sb) * sh.piece + ((s_in * sh.n_dtab + table) << 4);
+    // A lane's table is 256 contiguous bytes, but the lanes of a wave are n_dtab tables apart: stored straight from the
+    // registers every store instruction touches 64 different lines, 16 bytes each.  The wave turns its 64 x 16 entries
+    // through LDS (two halves of 8 entries, 144 bytes per lane: no bank conflicts either way) so that 8 consecutive lanes
+    // write one whole 128-byte line.
+    __shared__ v2d turn[256 * 9];
+    const int lane = threadIdx.x & 63;
+    v2d* mine = turn + (threadIdx.x & ~63) * 9;      // the wave's part; waves do not exchange anything
+    const int64_t wave_first = sample - lane;
 #pragma unroll
-    for (int x = 0; x < 16; ++x) o[x] = f[x];
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) mine[lane * 9 + x] = f[8 * h + x];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int l2 = 8 * i + (lane >> 3);      // whose entries this lane carries out
+            const int64_t smp = wave_first + l2;
+            const v2d val = mine[l2 * 9 + (lane & 7)];
+            if (smp < n_pad) {
+                const int64_t s_in = smp & (((int64_t)1 << sh.sb) - 1);
+                v2d* o = (v2d*)out + (smp >> sh.sb) * sh.piece + ((s_in * sh.n_dtab + table) << 4);
+                o[8 * h + (lane & 7)] = val;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // The 2x2 matrices the simulator applies (single gates and runs of gates on one qubit, multiplied out): one thread per
-// (sample, matrix), uniform control flow per wave as above.
+// (sample, matrix), uniform control flow per wave as above.  A gate multiplies the two rows of the product so far by
+// its own shape -- a rotation about z scales them, about x or y mixes them with real weights, X swaps them -- instead of
+// going through a general complex 2x2 product (8 complex multiplications per gate; a run of a GA genome has up to
+// gates-per-qubit factors), and the angles of up to four factors are loaded before the first of them is used.
+__device__ __forceinline__ void matrix_factor(int gate, double cn, double sn, v2d& a, v2d& b) {      // (a, b) <- G (a, b)
+    const double r = 0.70710678118654752440;
+    const v2d a0 = a, b0 = b;
+    if (gate == QK_H) { a = (v2d){r * (a0.x + b0.x), r * (a0.y + b0.y)}; b = (v2d){r * (a0.x - b0.x), r * (a0.y - b0.y)}; }
+    else if (gate == QK_X) { a = b0; b = a0; }
+    else if (gate == QK_SX) {      // 0.5 [[1 + i, 1 - i], [1 - i, 1 + i]]
+        a = (v2d){0.5 * ((a0.x - a0.y) + (b0.x + b0.y)), 0.5 * ((a0.x + a0.y) + (b0.y - b0.x))};
+        b = (v2d){0.5 * ((a0.x + a0.y) + (b0.x - b0.y)), 0.5 * ((a0.y - a0.x) + (b0.x + b0.y))};
+    }
+    else if (gate == QK_RX) {      // [[c, -i s], [-i s, c]]
+        a = (v2d){fma(cn, a0.x, sn * b0.y), fma(cn, a0.y, -(sn * b0.x))};
+        b = (v2d){fma(cn, b0.x, sn * a0.y), fma(cn, b0.y, -(sn * a0.x))};
+    }
+    else if (gate == QK_RZ) {      // diag(c - i s, c + i s)
+        a = (v2d){fma(cn, a0.x, sn * a0.y), fma(cn, a0.y, -(sn * a0.x))};
+        b = (v2d){fma(cn, b0.x, -(sn * b0.y)), fma(cn, b0.y, sn * b0.x)};
+    }
+    else if (gate == QK_P) { b = (v2d){fma(cn, b0.x, -(sn * b0.y)), fma(cn, b0.y, sn * b0.x)}; }      // diag(1, c + i s)
+    else {      // ry: [[c, -s], [s, c]]
+        a = (v2d){fma(cn, a0.x, -(sn * b0.x)), fma(cn, a0.y, -(sn * b0.y))};
+        b = (v2d){fma(cn, b0.x, sn * a0.x), fma(cn, b0.y, sn * a0.y)};
+    }
+}
+
 __global__ void __launch_bounds__(256) reg_matrix_kernel(const char* blob, const double2* cs, int64_t N, int64_t n_pad, double2* out) {
     const CWords hw = cwords(blob);
     const SideShape sh = side_shape(hw);
-    const int u_i = blockIdx.y;
+    const int lane = threadIdx.x & 63;
     const int64_t sample = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (sample >= n_pad) return;
+    const int64_t wave_first = sample - lane;
+    if (wave_first >= n_pad) return;      // (whole waves only: every lane of a wave carries entries out below)
     const int64_t src = sample < N ? sample : N - 1;
-    const CWords rec = cwords(blob + hw[15]) + 2 * u_i;
-    const int first = rec[0], count = rec[1];
-    const CWords fc = cwords(blob + hw[17]) + 2 * first;
-    v2d m0 = (v2d){1, 0}, m1 = (v2d){0, 0}, m2 = (v2d){0, 0}, m3 = (v2d){1, 0};
-    for (int k = 0; k < count; ++k) {
-        const int gate = fc[2 * k], expr = fc[2 * k + 1];
-        double cn = 1.0, sn = 0.0;
-        if (expr >= 0) {
-            const double2 g = cs[(int64_t)expr * N + src];
-            cn = g.x; sn = g.y;
+    // A sample's matrices are contiguous, 64 bytes each; the lanes of a wave are n_mat matrices apart.  A block does its
+    // share of the matrices two at a time and the wave turns each pair through LDS as reg_table_kernel does its halves:
+    // 8 consecutive lanes write 128 contiguous bytes, and the pairs of one sample follow each other from the same CU.
+    __shared__ v2d turn[256 * 9];
+    v2d* mine = turn + (threadIdx.x & ~63) * 9;
+    const int n_pairs = (sh.n_mat + 1) >> 1;
+    const int per_block = (n_pairs + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int p_end = min(n_pairs, ((int)blockIdx.y + 1) * per_block);
+    for (int p = (int)blockIdx.y * per_block; p < p_end; ++p) {
+        v2d m[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int u_i = 2 * p + half;
+            v2d m0 = (v2d){1, 0}, m1 = (v2d){0, 0}, m2 = (v2d){0, 0}, m3 = (v2d){1, 0};
+            if (u_i < sh.n_mat) {
+                const CWords rec = cwords(blob + hw[15]) + 2 * u_i;
+                const int first = rec[0], count = rec[1];
+                const CWords fc = cwords(blob + hw[17]) + 2 * first;
+                for (int k0 = 0; k0 < count; k0 += 4) {
+                    double2 g[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        g[j] = make_double2(1.0, 0.0);
+                        if (k0 + j < count) {
+                            const int expr = fc[2 * (k0 + j) + 1];
+                            if (expr >= 0) g[j] = cs[(int64_t)expr * N + src];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j < count) {
+                            const int gate = fc[2 * (k0 + j)];
+                            matrix_factor(gate, g[j].x, g[j].y, m0, m2);      // first column
+                            matrix_factor(gate, g[j].x, g[j].y, m1, m3);      // second column
+                        }
+                }
+            }
+            m[4 * half + 0] = m0; m[4 * half + 1] = m1; m[4 * half + 2] = m2; m[4 * half + 3] = m3;
         }
-        const double r = 0.70710678118654752440;
-        v2d g0, g1, g2, g3;
-        if (gate == QK_H) { g0 = (v2d){r, 0}; g1 = (v2d){r, 0}; g2 = (v2d){r, 0}; g3 = (v2d){-r, 0}; }
-        else if (gate == QK_X) { g0 = (v2d){0, 0}; g1 = (v2d){1, 0}; g2 = (v2d){1, 0}; g3 = (v2d){0, 0}; }
-        else if (gate == QK_SX) { g0 = (v2d){0.5, 0.5}; g1 = (v2d){0.5, -0.5}; g2 = (v2d){0.5, -0.5}; g3 = (v2d){0.5, 0.5}; }
-        else if (gate == QK_RX) { g0 = (v2d){cn, 0}; g1 = (v2d){0, -sn}; g2 = (v2d){0, -sn}; g3 = (v2d){cn, 0}; }
-        else if (gate == QK_RZ) { g0 = (v2d){cn, -sn}; g1 = (v2d){0, 0}; g2 = (v2d){0, 0}; g3 = (v2d){cn, sn}; }
-        else if (gate == QK_P) { g0 = (v2d){1, 0}; g1 = (v2d){0, 0}; g2 = (v2d){0, 0}; g3 = (v2d){cn, sn}; }
-        else { g0 = (v2d){cn, 0}; g1 = (v2d){-sn, 0}; g2 = (v2d){sn, 0}; g3 = (v2d){cn, 0}; }      // ry
-        if (k == 0) { m0 = g0; m1 = g1; m2 = g2; m3 = g3; }
-        else {      // M <- G M
-            const v2d n0 = cmul(g0, m0) + cmul(g1, m2), n1 = cmul(g0, m1) + cmul(g1, m3);
-            const v2d n2 = cmul(g2, m0) + cmul(g3, m2), n3 = cmul(g2, m1) + cmul(g3, m3);
-            m0 = n0; m1 = n1; m2 = n2; m3 = n3;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) mine[lane * 9 + x] = m[x];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        const int e = lane & 7;
+        const bool exists = 2 * p + (e >> 2) < sh.n_mat;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int l2 = 8 * i + (lane >> 3);
+            const int64_t smp = wave_first + l2;
+            const v2d val = mine[l2 * 9 + e];
+            if (exists && smp < n_pad) {
+                const int64_t s_in = smp & (((int64_t)1 << sh.sb) - 1);
+                v2d* o = (v2d*)out + (smp >> sh.sb) * sh.piece + (((int64_t)sh.n_dtab << sh.sb) << 4) + ((s_in * sh.n_mat + 2 * p) << 2);
+                o[e] = val;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    const int64_t s_in = sample & (((int64_t)1 << sh.sb) - 1);
-    v2d* o = (v2d*)out + (sample >> sh.sb) * sh.piece + (((int64_t)sh.n_dtab << sh.sb) << 4) + ((s_in * sh.n_mat + u_i) << 2);
-    o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m3;
 }
 
 bool reg_rdm_mode_ok(const qk_circuit& c) {
@@ -879,9 +958,14 @@ int launch_reg_side(const qk_circuit& c, const void* blob_dev, const double2* cs
     if (n_dtab > 0)
         hipLaunchKernelGGL(reg_table_kernel, dim3((unsigned)((n_pad + 255) / 256), (unsigned)n_dtab), dim3(256), 0, stream,
                            (const char*)blob_dev, cs, N, n_pad, (double2*)tabs);
-    if (H->n_mat > 0)
-        hipLaunchKernelGGL(reg_matrix_kernel, dim3((unsigned)((n_pad + 255) / 256), (unsigned)H->n_mat), dim3(256), 0, stream,
+    if (H->n_mat > 0) {
+        // pairs of matrices; one block takes all pairs of its 256 samples unless the batch is too small to fill the chip that way
+        const int64_t bx = (n_pad + 255) / 256;
+        const int n_pairs = (H->n_mat + 1) / 2;
+        const int by = (int)std::max<int64_t>(1, std::min<int64_t>(n_pairs, (1024 + bx - 1) / bx));
+        hipLaunchKernelGGL(reg_matrix_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, stream,
                            (const char*)blob_dev, cs, N, n_pad, (double2*)tabs);
+    }
     QK_HIP(hipGetLastError());
     return QK_OK;
 }
