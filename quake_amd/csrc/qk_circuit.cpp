@@ -1051,8 +1051,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         const size_t nd = (n_slot / 64 + waves - 1) / waves + (t_slot + waves - 1) / waves;    // fetch instructions per wave and sample group
         if (std::getenv("QK_REG_DEBUG")) std::fprintf(stderr, "[reg plan] Lv=%d fits=%d nd=%zu lds=%zu limit=%zu tabs=%zu terms=%zu mats=%zu\n", Lv, (int)fits, nd, lds, lds_limit, tabs.size(), rterms.size(), rmats.size());
         if (!(fits && nd <= 64 && lds <= lds_limit)) return false;
-        if (dry_lds) {      // (bit 40: product-state tables are built in the kernel; bit 41: 8 amplitudes per thread)
-            *dry_lds = lds | (all_h ? (size_t)0 : (size_t)1 << 40) | (RB == 3 ? (size_t)1 << 41 : (size_t)0);
+        if (dry_lds) {      // (bit 40: product-state tables are built in the kernel; bit 41: 8 amplitudes per thread; bit 42: 2n or more per-thread terms)
+            *dry_lds = lds | (all_h ? (size_t)0 : (size_t)1 << 40) | (RB == 3 ? (size_t)1 << 41 : (size_t)0) |
+                       (rterms.size() >= (size_t)(2 * n) ? (size_t)1 << 42 : (size_t)0);
             return true;
         }
         {
@@ -1131,12 +1132,21 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         bool done = false;
         if (lv_env >= kRegMinQubits && lv_env <= kRegPackMaxWidth) done = plan_q(lv_env, (size_t)160 * 1024);
         int best = 0, best_waves = 0;
+        bool widest = false;
         for (int Lv = kRegMinQubits; Lv <= kRegPackMaxWidth && !done; ++Lv) {
             size_t lds = 0;
             if (!plan_q(Lv, (size_t)160 * 1024, &lds)) continue;
             // a first layer that is not all Hadamards (GA genomes) has its product-state tables built inside the kernel, a
             // wave per sample and a barrier behind it: single-wave workgroups (L = 10) keep that wave-local
+            // (end of round 3, eight random genomes of two gate alphabets at 7 / 8 / 9 qubits, tools/sim_bench.py --genomes 4: L = 11
+            // or 12 wins or loses 5-20 % genome by genome, with no sign that the plan's counts predict; L = 10 stays)
             if (((lds >> 40) & 1) && n >= 7) { best = Lv; break; }      // (6 qubits and below: 16+ samples per wave either way, the count decides)
+            // Diagonal stages with a layer's worth of terms that stay per thread at the narrowest width (ZZ map with full
+            // entanglement: 24 / 32 / 48 terms at 7 / 8 / 9 qubits): the widest workgroup that fits, whose tables per
+            // register position are affordable and whose term records are read once for 8 to 32 samples -- 4 GiB of Psi,
+            // L = 10 -> 12: 9 qubits 4.45 -> 3.32 ms, 8 qubits 3.64 -> 3.15, 7 qubits 4.86 -> 4.38.
+            if (Lv == kRegMinQubits && ((lds >> 42) & 1) && n >= 7) widest = true;
+            if (widest) { best = Lv; continue; }
             const int rb = ((lds >> 41) & 1) ? 3 : 4;
             const int waves = std::min(rb == 3 ? 16 : 12, (int)((size_t)160 * 1024 / (lds & (((size_t)1 << 40) - 1))) * ((1 << (Lv - rb)) / 64));
             if (waves > best_waves) { best_waves = waves; best = Lv; }

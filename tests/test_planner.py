@@ -167,3 +167,14 @@ def test_register_plan_ratio_tables_need_many_register_thread_terms():
     x13 = ParameterVector("x", 13)
     full13 = _reg_plan(fm.zz_featuremap(x13, 13, 2, entanglement="full"))
     assert full13["ratio_positions"] == 8 and full13["tables"] == 3 * 4 + 3 * 8      # (A, Blo, 2 x Bhi) and (Qlo, 2 x Qhi) per position
+
+
+def test_register_plan_takes_the_widest_workgroup_for_term_heavy_diagonal_stages():
+    """qk_circuit.cpp section 4, packed plans below 10 qubits: a ZZ map with full entanglement leaves 2n or more terms per
+    thread at the narrowest width (10), so the planner takes the widest workgroup that fits (12: 4096 amplitudes) -- where the
+    ratio tables per register position are affordable -- while the linear map keeps the narrowest."""
+    for n, samples in ((7, 32), (8, 16), (9, 8)):
+        full = _reg_plan(fm.zz_featuremap(ParameterVector("x", n), n, 2, entanglement="full"))
+        assert full and full["samples"] == samples and full["ratio_positions"] > 0, (n, full)
+        lin = _reg_plan(zz(n, 2))
+        assert lin and lin["samples"] * (1 << n) == 1024, (n, lin)

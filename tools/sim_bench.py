@@ -32,6 +32,15 @@ def circuits(n):
         g, xi = genetic.to_quantum(genes, gd, n, 8, n, physical_qubits=list(range(n)), verbose=False)
         if g.num_parameters == n:
             extra["genome_g8"] = g
+        # --genomes K: K more chromosomes per gate alphabet (the full one above and the hardware-native one of the
+        # reference's examples), for rules that must hold for genomes in general and not for one of them
+        hw = {"single_non_parametric": ["Id", "X", "SX"], "single_parametric": ["RZ", "RZ"], "two_non_parametric": ["ECR"], "two_parametric": []}
+        for k in range(N_GENOMES):
+            for tag, alphabet in (("full", gd), ("hw", hw)):
+                genes = genetic.initial_population(1, n, 8, alphabet, n, rng=np.random.default_rng(100 + k))[0]
+                g, xi = genetic.to_quantum(genes, alphabet, n, 8, n, physical_qubits=list(range(n)), verbose=False)
+                if g.num_parameters == n:
+                    extra["genome_%s%d" % (tag, k)] = g
     return {"h_only": h, "z_r1": hp, "z_r2": fm.z_featuremap(x, n, 2), "zz_r1": fm.zz_featuremap(x, n, 1), "zz_r2": fm.zz_featuremap(x, n, 2),
             "custom1_r1": fm.custom1_featuremap(x, n, 1), "custom2_r1": fm.custom2_featuremap(x, n, 1),
             "custom1_r2": fm.custom1_featuremap(x, n, 2), "custom2_r2": fm.custom2_featuremap(x, n, 2),
@@ -41,8 +50,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--qubits", type=int, nargs="+", default=[16, 13, 12, 10, 8])
 ap.add_argument("--gib", type=float, default=4.0, help="Psi bytes per run")
 ap.add_argument("--maps", nargs="*", default=None)
+ap.add_argument("--genomes", type=int, default=0, help="extra random chromosomes per gate alphabet (maps genome_full<k>, genome_hw<k>)")
 ap.add_argument("--fill", action="store_true", help="also time a plain device fill / copy of the same size")
 a = ap.parse_args()
+N_GENOMES = a.genomes
 if a.fill:
     buf = torch.empty(int(a.gib * 2**30) // 8, dtype=torch.float64, device="cuda")
     src = torch.ones_like(buf)
@@ -60,7 +71,7 @@ for n in a.qubits:
     X = torch.from_numpy(np.random.default_rng(1).uniform(-1.5, 1.5, size=(N, n))).cuda()
     psi = torch.empty((N, 1 << n), dtype=torch.complex128, device="cuda")
     for name, c in circuits(n).items():
-        if a.maps and name not in a.maps: continue
+        if a.maps and name not in a.maps and not (a.genomes and name.startswith("genome_") and "genome" in a.maps): continue
         dc = qdev.DeviceCircuit(c)
         Xn = X[:, :dc.n_params].contiguous() if dc.n_params else X[:, :0].contiguous()
         dc.simulate(Xn, out=psi); torch.cuda.synchronize()
