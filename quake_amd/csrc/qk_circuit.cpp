@@ -93,14 +93,27 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     std::vector<std::vector<Factor>> comps;
     {
         auto single = [](const Item& it) { return it.diag ? (it.kind == TM_P || it.kind == TM_RZ) : it.kind == ST_U1; };
+        // Circuits whose diagonal gates are all single-qubit ones (GA genomes: rz / p between sx, x, ecr, cx): a chain with
+        // ONE non-diagonal gate and diagonal gates around it is a composite as well -- rz sx rz is how the hardware-native
+        // alphabet writes any rotation, and left apart each rz becomes a term of a diagonal stage of its own (three phase
+        // tables per stage and sample, a walk over every amplitude) where one general butterfly does it.  Not where the
+        // chain is the first thing on its qubit and starts with the non-diagonal gate (h p: the first gate joins the product
+        // state, the phase its diagonal stage: the Z map), and not in circuits with cz / zz terms, whose stages exist anyway.
+        static const bool env_off = [] { const char* e = std::getenv("QK_PLAN_RZ_CHAINS"); return e && std::atoi(e) == 0; }();
+        bool two_qubit_diag = false;
+        for (const Item& it : items) two_qubit_diag = two_qubit_diag || (it.diag && it.q1 >= 0);
+        const bool rz_chains = !two_qubit_diag && !env_off;
         std::vector<std::vector<Item>> chain(n);
         std::vector<Item> out;
+        std::vector<bool> seen(n, false);      // something has acted on the qubit before the chain
         bool any = false;
         auto flush_q = [&](int q) {
             std::vector<Item>& ch = chain[q];
             int nd = 0;
             for (const Item& g : ch) nd += g.diag ? 0 : 1;
-            if (nd < 2) {
+            const bool around = rz_chains && nd == 1 && ch.size() >= 2 && !(!seen[q] && !ch[0].diag);
+            if (!ch.empty()) seen[q] = true;
+            if (nd < 2 && !around) {
                 out.insert(out.end(), ch.begin(), ch.end());
             } else {
                 // the whole chain, diagonal gates at its head and tail included: a composite that is the first
@@ -118,6 +131,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             if (single(it)) { chain[it.q0].push_back(it); continue; }
             flush_q(it.q0);
             if (it.q1 >= 0) flush_q(it.q1);
+            seen[it.q0] = true;
+            if (it.q1 >= 0) seen[it.q1] = true;
             out.push_back(it);
         }
         for (int q = 0; q < n; ++q) flush_q(q);
@@ -1061,6 +1076,19 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             RegHeader H{};
             H.L = Lv;
             H.nq = n;
+            if (const char* dbg = std::getenv("QK_REG_DEBUG"); dbg && std::atoi(dbg) >= 2) {      // the layouts and their ops, one line per segment
+                static const char* const kind_name[] = {"init", "diag", "u1", "cx", "cxt", "ecr"};
+                for (const RegSeg& sg : segs) {
+                    std::fprintf(stderr, "[reg plan]   layout {%d %d %d %d}:", sg.g[0], sg.g[1], sg.g[2], sg.g[3]);
+                    for (int k = sg.op0; k < sg.op1; ++k) {
+                        const RegOp& o = rops[(size_t)k];
+                        if (o.kind == RG_DIAG) std::fprintf(stderr, " diag(tx %d rt %d%s)", o.nTX, o.nRT, (o.flags & 512) ? " ratio" : "");
+                        else if (o.kind == RG_U1) std::fprintf(stderr, " u1(mask %x)", (unsigned)o.a);
+                        else std::fprintf(stderr, " %s(%d,%d)", kind_name[o.kind], o.a, o.b);
+                    }
+                    std::fprintf(stderr, "\n");
+                }
+            }
             H.n_seg = (int)segs.size(); H.n_op = (int)rops.size(); H.n_tab = (int)tabs.size(); H.n_term = (int)rterms.size();
             H.n_expr = (int)rexprs.size(); H.n_mat = (int)rmats.size(); H.n_comp = 0; H.n_fact = (int)rfacts.size();
             H.init_h = (all_h ? 1 : 0) | (tab_single ? 2 : 0);

@@ -178,3 +178,39 @@ def test_register_plan_takes_the_widest_workgroup_for_term_heavy_diagonal_stages
         assert full and full["samples"] == samples and full["ratio_positions"] > 0, (n, full)
         lin = _reg_plan(zz(n, 2))
         assert lin and lin["samples"] * (1 << n) == 1024, (n, lin)
+
+
+def test_rz_around_one_gate_is_one_matrix_when_no_two_qubit_diagonal_term_exists():
+    """qk_circuit.cpp section 1b: in circuits whose diagonal gates are all single-qubit ones (GA genomes of the hardware-native
+    alphabet: rz sx rz between ecr gates) a chain with ONE non-diagonal gate and rz around it becomes a composite matrix
+    and leaves no diagonal stage behind; a chain that is the first thing on its qubit and starts with its non-diagonal gate
+    (h p: the Z map) keeps gate and phase apart, and so does every chain of a circuit with cz / zz terms."""
+    from quake_amd.circuit import QuantumCircuit
+    x = ParameterVector("x", 4)
+
+    def counts(c):
+        s = plan(c)[0]
+        m = re.search(r"composite u1 (\d+), cx (\d+), ecr (\d+), diagonal stages (\d+) with (\d+) terms", s)
+        return {"uc": int(m.group(1)), "diag": int(m.group(4)), "terms": int(m.group(5))}, s
+
+    c = QuantumCircuit(4)
+    for q in range(4):
+        c.sx(q)
+    c.ecr(0, 1); c.ecr(2, 3)
+    for q in range(4):
+        c.rz(x[q], q); c.sx(q); c.rz(x[(q + 1) % 4] * 0.5, q)
+    c.ecr(1, 2)
+    for q in (1, 2):
+        c.sx(q); c.rz(x[q], q)
+    got, s = counts(c)
+    assert got == {"uc": 6, "diag": 0, "terms": 0}, s
+    # the same chains next to a cz: as before (two diagonal stages take the rz terms)
+    c2 = QuantumCircuit(4)
+    for ins in c.data:
+        c2.data.append(ins)
+    c2.cz(0, 3)
+    got2, s2 = counts(c2)
+    assert got2["uc"] == 0 and got2["diag"] >= 2 and got2["terms"] == 11, s2
+    # h p as the first thing on a qubit: product state + one diagonal stage (the Z map's shape)
+    got3, s3 = counts(fm.z_featuremap(x, 4, 1))
+    assert got3 == {"uc": 0, "diag": 1, "terms": 4}, s3
