@@ -97,8 +97,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         // ONE non-diagonal gate and diagonal gates around it is a composite as well -- rz sx rz is how the hardware-native
         // alphabet writes any rotation, and left apart each rz becomes a term of a diagonal stage of its own (three phase
         // tables per stage and sample, a walk over every amplitude) where one general butterfly does it.  Not where the
-        // chain is the first thing on its qubit and starts with the non-diagonal gate (h p: the first gate joins the product
-        // state, the phase its diagonal stage: the Z map), and not in circuits with cz / zz terms, whose stages exist anyway.
+        // chain is the first thing on its qubit and starts with a Hadamard (h p: the Hadamards are the constant product
+        // state, the phases one diagonal stage: the Z map), and not in circuits with cz / zz terms, whose stages exist anyway.
         static const bool env_off = [] { const char* e = std::getenv("QK_PLAN_RZ_CHAINS"); return e && std::atoi(e) == 0; }();
         bool two_qubit_diag = false;
         for (const Item& it : items) two_qubit_diag = two_qubit_diag || (it.diag && it.q1 >= 0);
@@ -111,7 +111,7 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             std::vector<Item>& ch = chain[q];
             int nd = 0;
             for (const Item& g : ch) nd += g.diag ? 0 : 1;
-            const bool around = rz_chains && nd == 1 && ch.size() >= 2 && !(!seen[q] && !ch[0].diag);
+            const bool around = rz_chains && nd == 1 && ch.size() >= 2 && !(!seen[q] && !ch[0].diag && ch[0].gate == QK_H);
             if (!ch.empty()) seen[q] = true;
             if (nd < 2 && !around) {
                 out.insert(out.end(), ch.begin(), ch.end());

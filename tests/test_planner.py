@@ -183,8 +183,8 @@ def test_register_plan_takes_the_widest_workgroup_for_term_heavy_diagonal_stages
 def test_rz_around_one_gate_is_one_matrix_when_no_two_qubit_diagonal_term_exists():
     """qk_circuit.cpp section 1b: in circuits whose diagonal gates are all single-qubit ones (GA genomes of the hardware-native
     alphabet: rz sx rz between ecr gates) a chain with ONE non-diagonal gate and rz around it becomes a composite matrix
-    and leaves no diagonal stage behind; a chain that is the first thing on its qubit and starts with its non-diagonal gate
-    (h p: the Z map) keeps gate and phase apart, and so does every chain of a circuit with cz / zz terms."""
+    and leaves no diagonal stage behind; a chain that is the first thing on its qubit and starts with a Hadamard (h p: the
+    Z map) keeps gate and phase apart, and so does every chain of a circuit with cz / zz terms."""
     from quake_amd.circuit import QuantumCircuit
     x = ParameterVector("x", 4)
 
@@ -214,3 +214,6 @@ def test_rz_around_one_gate_is_one_matrix_when_no_two_qubit_diagonal_term_exists
     # h p as the first thing on a qubit: product state + one diagonal stage (the Z map's shape)
     got3, s3 = counts(fm.z_featuremap(x, 4, 1))
     assert got3 == {"uc": 0, "diag": 1, "terms": 4}, s3
+    # ry rz as the first thing on a qubit: the whole run joins the product state
+    got4, s4 = counts(fm.custom2_featuremap(x, 4, 1))
+    assert got4["diag"] == 0 and "product-state gates 4 (4 composite)" in s4, s4
