@@ -313,6 +313,28 @@ def test_register_resident_ratio_tables(n, N):
     del psi
 
 
+@pytest.mark.parametrize("n,N,seed", [(6, 70000, 100), (7, 40000, 101), (8, 16384 + 3, 101), (9, 8192 + 5, 100), (10, 8192 + 1, 102),
+                                      (12, 1024 + 3, 103), (13, 512 + 1, 100)])
+def test_hardware_native_genomes_large_batch(n, N, seed):
+    """GA genomes of the hardware-native alphabet of the reference's examples ({id, x, sx, rz, ecr}: every rotation is
+    rz sx rz) at batch sizes that take the register-resident kernel: the planner multiplies each run of rz around one
+    sx / x into one matrix per sample (qk_circuit.cpp section 1b, end of round 3) and the pre-pass kernels write those
+    matrices through LDS in whole lines.  Rows sampled against the oracle, every row's norm."""
+    import torch
+    from quake_amd import device as qdev
+    hw = {"single_non_parametric": ["Id", "X", "SX"], "single_parametric": ["RZ", "RZ"], "two_non_parametric": ["ECR"], "two_parametric": []}
+    genes = genetic.initial_population(1, n, 8, hw, n, rng=np.random.default_rng(seed))[0]
+    c, cols = genetic.to_quantum(genes, hw, n, 8, n, physical_qubits=list(range(n)), verbose=False)
+    dc = qdev.DeviceCircuit(c)
+    assert "register-resident plan" in dc.handle.plan_summary, dc.handle.plan_summary
+    X = np.random.default_rng(seed + n).uniform(0.02, 0.98, size=(N, n))[:, cols]      # (get_subsample's range: asin stays real)
+    psi = dc.simulate(torch.from_numpy(np.ascontiguousarray(X)).cuda())
+    rows = np.unique(np.concatenate([[0, 1, N - 2, N - 1], np.random.default_rng(n).integers(0, N, 8)]))
+    assert np.abs(psi[torch.from_numpy(rows).cuda()].cpu().numpy() - psi_from_compiled(c, X[rows])).max() < TOL_PSI
+    assert float(((psi.real ** 2 + psi.imag ** 2).sum(dim=1) - 1.0).abs().max()) < 1e-12
+    del psi
+
+
 def test_register_resident_simulator_in_chunks():
     """A batch whose pre-pass tables would exceed 1 GiB goes through the register-resident path in chunks of whole sample
     groups (6 qubits, ZZ r = 2: 1376 bytes of angles and tables per sample, 800 003 samples = a chunk of 2^30 / 1376 samples rounded down to whole groups and the rest, the second one
