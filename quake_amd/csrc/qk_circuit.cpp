@@ -49,8 +49,14 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
 
     // ---- 1. classify + peephole ------------------------------------------
     std::vector<Item> items;
+    // basis[q]: 0 / 1 while only id, x and diagonal gates have acted on q -- the qubit is still |0> or |1> up to a phase --
+    // and -1 after anything else.  A cx whose control is still |0> is the identity and a cz with either qubit still |0> as
+    // well; a cx whose control is |1> is an x on its target.  (GA genomes draw their gates at random: the first gate on a
+    // qubit is often the control of a cx, and without it the qubit's single-qubit gates join the product state.)
+    static const bool basis_off = [] { const char* e = std::getenv("QK_PLAN_BASIS_CONTROLS"); return e && std::atoi(e) == 0; }();
+    std::vector<int> basis(n, basis_off ? -1 : 0);
     for (int i = 0; i < n_ops; ++i) {
-        const qk_op& o = ops[i];
+        qk_op o = ops[i];
         const bool two = (o.gate == QK_CX || o.gate == QK_CZ || o.gate == QK_ECR);
         const bool par = (o.gate == QK_RX || o.gate == QK_RY || o.gate == QK_RZ || o.gate == QK_P);
         if (o.gate < QK_ID || o.gate > QK_ECR) return fail(QK_ERR_INVALID, "unknown gate code in op table");
@@ -59,6 +65,13 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         if (par && (o.expr < 0 || o.expr >= n_expr))
             return fail(QK_ERR_INVALID, "parametric gate without a valid angle program");
         if (o.gate == QK_ID) continue;
+        if (o.gate == QK_CX && basis[o.q0] == 0) continue;
+        if (o.gate == QK_CZ && (basis[o.q0] == 0 || basis[o.q1] == 0)) continue;
+        if (o.gate == QK_CX && basis[o.q0] == 1) { o.gate = QK_X; o.q0 = o.q1; o.q1 = -1; }
+        if (o.gate == QK_X) basis[o.q0] = basis[o.q0] < 0 ? -1 : 1 - basis[o.q0];
+        else if (o.gate == QK_CX) basis[o.q1] = -1;      // (control not a basis state: the target is entangled with it)
+        else if (o.gate == QK_ECR) basis[o.q0] = basis[o.q1] = -1;
+        else if (o.gate != QK_RZ && o.gate != QK_P && o.gate != QK_CZ) basis[o.q0] = -1;
         if (o.gate == QK_CX && i + 2 < n_ops) {
             const qk_op& p = ops[i + 1];
             const qk_op& x2 = ops[i + 2];

@@ -335,6 +335,55 @@ def test_hardware_native_genomes_large_batch(n, N, seed):
     del psi
 
 
+@pytest.mark.parametrize("n,N,seed", [(3, 7, 0), (5, 33, 1), (8, 16384 + 1, 2), (10, 8192 + 3, 3), (12, 1024 + 1, 4), (14, 5, 5)])
+def test_cx_and_cz_on_basis_state_controls(n, N, seed):
+    """Circuits that open with id / x / rz / p / cz / cx on every qubit -- controls that are still |0> or |1> when their
+    cx or cz comes, which the planner drops or turns into an x (qk_circuit.cpp section 1) -- followed by gates of every
+    kind: the oracle applies every gate as written."""
+    rng = np.random.default_rng(500 + seed)
+    F = 3
+    x = qc.ParameterVector("x", F)
+    c = qc.QuantumCircuit(n)
+    for k in range(F):
+        c.rz(x[k], k % n)
+    for _ in range(4 * n):      # the opening: basis states and phases only
+        g = int(rng.integers(0, 6))
+        q = int(rng.integers(0, n))
+        r = int((q + 1 + rng.integers(0, n - 1)) % n)
+        a = x[int(rng.integers(0, F))] * float(rng.uniform(0.5, 2.0))
+        if g == 0: c.id(q)
+        elif g == 1: c.x(q)
+        elif g == 2: c.rz(a, q)
+        elif g == 3: c.p(a, q)
+        elif g == 4: c.cz(q, r)
+        else: c.cx(q, r)
+    for _ in range(3 * n):      # then everything
+        g = int(rng.integers(0, 9))
+        q = int(rng.integers(0, n))
+        r = int((q + 1 + rng.integers(0, n - 1)) % n)
+        a = x[int(rng.integers(0, F))] * float(rng.uniform(0.5, 2.0))
+        if g == 0: c.h(q)
+        elif g == 1: c.sx(q)
+        elif g == 2: c.ry(a, q)
+        elif g == 3: c.rx(a, q)
+        elif g == 4: c.cx(q, r)
+        elif g == 5: c.cz(q, r)
+        elif g == 6: c.ecr(q, r)
+        elif g == 7: c.x(q)
+        else: c.p(a, q)
+    X = synth_X(N, F, "scaled", 700 + seed)
+    got = HipFidelityKernel(c).statevectors(X) if N <= 64 else None
+    if got is None:
+        import torch
+        from quake_amd import device as qdev
+        psi = qdev.DeviceCircuit(c).simulate(torch.from_numpy(X).cuda())
+        rows = np.unique(np.concatenate([[0, 1, N - 1], rng.integers(0, N, 6)]))
+        assert np.abs(psi[torch.from_numpy(rows).cuda()].cpu().numpy() - psi_from_compiled(c, X[rows])).max() < TOL_PSI
+        del psi
+    else:
+        assert np.abs(got - psi_from_compiled(c, X)).max() < TOL_PSI
+
+
 def test_register_resident_simulator_in_chunks():
     """A batch whose pre-pass tables would exceed 1 GiB goes through the register-resident path in chunks of whole sample
     groups (6 qubits, ZZ r = 2: 1376 bytes of angles and tables per sample, 800 003 samples = a chunk of 2^30 / 1376 samples rounded down to whole groups and the rest, the second one

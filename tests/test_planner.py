@@ -217,3 +217,32 @@ def test_rz_around_one_gate_is_one_matrix_when_no_two_qubit_diagonal_term_exists
     # ry rz as the first thing on a qubit: the whole run joins the product state
     got4, s4 = counts(fm.custom2_featuremap(x, 4, 1))
     assert got4["diag"] == 0 and "product-state gates 4 (4 composite)" in s4, s4
+
+
+def test_controls_that_are_still_basis_states_cost_nothing():
+    """qk_circuit.cpp section 1: while only id, x and diagonal gates have acted on a qubit it is |0> or |1> up to a phase, so
+    a cx it controls is the identity (|0>) or an x on the target (|1>), and a cz with such a |0> qubit is the identity.  GA
+    genomes start many qubits that way; without the cx the qubit's single-qubit gates join the product state."""
+    from quake_amd.circuit import QuantumCircuit
+    x = ParameterVector("x", 3)
+
+    def counts(c):
+        s = plan(c)[0]
+        m = re.search(r"gates (\d+): product-state gates (\d+) .*?then u1 (\d+), composite u1 (\d+), cx (\d+), ecr (\d+), diagonal stages (\d+) with (\d+) terms", s)
+        return {"gates": int(m.group(1)), "init": int(m.group(2)), "cx": int(m.group(5)), "terms": int(m.group(8))}, s
+
+    c = QuantumCircuit(3)
+    c.rz(x[0], 0)                 # a phase: q0 is still |0>
+    c.cx(0, 1)                    # identity
+    c.ry(x[1], 1); c.rx(x[2], 1)  # q1's first gates: product state
+    c.x(2); c.cx(2, 0)            # q2 is |1>: an x on q0, which stays a basis state
+    c.cx(0, 1)                    # q0 is |1> now: an x on q1
+    c.cz(0, 2)                    # neither is |0>: stays
+    c.h(0); c.cx(0, 2)            # a real cx
+    got, s = counts(c)
+    assert got["cx"] == 1 and got["terms"] == 2, s      # rz and cz are the two diagonal terms
+    # nothing is dropped once the control has seen a non-diagonal gate
+    c2 = QuantumCircuit(3)
+    c2.h(0); c2.cx(0, 1); c2.sx(2); c2.cx(2, 1); c2.cz(0, 2)
+    got2, s2 = counts(c2)
+    assert got2["cx"] == 2 and got2["terms"] == 1, s2
