@@ -53,8 +53,24 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     // and -1 after anything else.  A cx whose control is still |0> is the identity and a cz with either qubit still |0> as
     // well; a cx whose control is |1> is an x on its target.  (GA genomes draw their gates at random: the first gate on a
     // qubit is often the control of a cx, and without it the qubit's single-qubit gates join the product state.)
+    // An ecr is rz(pi/2) on its first qubit and sx on its second, then cx(first, second), then x on the first (exact): while
+    // its first qubit is still a basis state the cx is nothing or an x, and the whole gate is single-qubit gates -- the
+    // hardware-native genomes open many qubits that way.  The rz(pi/2) is a phase that must stay: its angle is one more
+    // constant program at the end of the circuit's own.
     static const bool basis_off = [] { const char* e = std::getenv("QK_PLAN_BASIS_CONTROLS"); return e && std::atoi(e) == 0; }();
     std::vector<int> basis(n, basis_off ? -1 : 0);
+    std::vector<int32_t> eoff(expr_off ? expr_off : nullptr, expr_off ? expr_off + n_expr + 1 : nullptr);
+    if (eoff.empty()) eoff.push_back(0);
+    int half_pi_expr = -1;
+    auto half_pi = [&]() {
+        if (half_pi_expr < 0) {
+            c.consts.push_back(1.57079632679489661923);
+            c.prog.push_back(qk_instr{QK_EX_CONST, (int32_t)c.consts.size() - 1});
+            eoff.push_back((int32_t)c.prog.size());
+            half_pi_expr = (int)eoff.size() - 2;
+        }
+        return half_pi_expr;
+    };
     for (int i = 0; i < n_ops; ++i) {
         qk_op o = ops[i];
         const bool two = (o.gate == QK_CX || o.gate == QK_CZ || o.gate == QK_ECR);
@@ -68,6 +84,15 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         if (o.gate == QK_CX && basis[o.q0] == 0) continue;
         if (o.gate == QK_CZ && (basis[o.q0] == 0 || basis[o.q1] == 0)) continue;
         if (o.gate == QK_CX && basis[o.q0] == 1) { o.gate = QK_X; o.q0 = o.q1; o.q1 = -1; }
+        if (o.gate == QK_ECR && basis[o.q0] >= 0) {
+            items.push_back({true, TM_RZ, 0, o.q0, -1, half_pi()});
+            items.push_back({false, ST_U1, QK_SX, o.q1, -1, -1});
+            if (basis[o.q0] == 1) items.push_back({false, ST_U1, QK_X, o.q1, -1, -1});
+            items.push_back({false, ST_U1, QK_X, o.q0, -1, -1});
+            basis[o.q0] = 1 - basis[o.q0];
+            basis[o.q1] = -1;
+            continue;
+        }
         if (o.gate == QK_X) basis[o.q0] = basis[o.q0] < 0 ? -1 : 1 - basis[o.q0];
         else if (o.gate == QK_CX) basis[o.q1] = -1;      // (control not a basis state: the target is entangled with it)
         else if (o.gate == QK_ECR) basis[o.q0] = basis[o.q1] = -1;
@@ -95,6 +120,8 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         }
     }
     c.n_gates = (int)items.size();
+    expr_off = eoff.data();      // (the caller's angle programs, and the constant above when an ecr needed it)
+    n_expr = (int)eoff.size() - 1;
 
     // ---- 1b. runs of single-qubit gates on one qubit -> one composite matrix -------------------
     // chain[q]: the single-qubit items on q since the last two-qubit item that touched q.  Gates on

@@ -337,17 +337,18 @@ def test_hardware_native_genomes_large_batch(n, N, seed):
 
 @pytest.mark.parametrize("n,N,seed", [(3, 7, 0), (5, 33, 1), (8, 16384 + 1, 2), (10, 8192 + 3, 3), (12, 1024 + 1, 4), (14, 5, 5)])
 def test_cx_and_cz_on_basis_state_controls(n, N, seed):
-    """Circuits that open with id / x / rz / p / cz / cx on every qubit -- controls that are still |0> or |1> when their
-    cx or cz comes, which the planner drops or turns into an x (qk_circuit.cpp section 1) -- followed by gates of every
-    kind: the oracle applies every gate as written."""
+    """Circuits that open with id / x / rz / p / cz / cx / ecr on every qubit -- controls that are still |0> or |1> when
+    their cx or cz comes, which the planner drops or turns into an x, and ecr gates on such a first qubit, which it writes
+    as rz(pi/2), sx and x (qk_circuit.cpp section 1) -- followed by gates of every kind: the oracle applies every gate as
+    written."""
     rng = np.random.default_rng(500 + seed)
     F = 3
     x = qc.ParameterVector("x", F)
     c = qc.QuantumCircuit(n)
     for k in range(F):
         c.rz(x[k], k % n)
-    for _ in range(4 * n):      # the opening: basis states and phases only
-        g = int(rng.integers(0, 6))
+    for _ in range(4 * n):      # the opening: basis states and phases, and ecr gates whose first qubit may still be one
+        g = int(rng.integers(0, 7))
         q = int(rng.integers(0, n))
         r = int((q + 1 + rng.integers(0, n - 1)) % n)
         a = x[int(rng.integers(0, F))] * float(rng.uniform(0.5, 2.0))
@@ -356,7 +357,8 @@ def test_cx_and_cz_on_basis_state_controls(n, N, seed):
         elif g == 2: c.rz(a, q)
         elif g == 3: c.p(a, q)
         elif g == 4: c.cz(q, r)
-        else: c.cx(q, r)
+        elif g == 5: c.cx(q, r)
+        else: c.ecr(q, r)
     for _ in range(3 * n):      # then everything
         g = int(rng.integers(0, 9))
         q = int(rng.integers(0, n))

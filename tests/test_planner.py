@@ -241,6 +241,11 @@ def test_controls_that_are_still_basis_states_cost_nothing():
     c.h(0); c.cx(0, 2)            # a real cx
     got, s = counts(c)
     assert got["cx"] == 1 and got["terms"] == 2, s      # rz and cz are the two diagonal terms
+    # an ecr whose first qubit is still a basis state is single-qubit gates (and a constant angle program for its phase)
+    c3 = QuantumCircuit(3)
+    c3.ecr(0, 1); c3.x(2); c3.ecr(2, 0); c3.ecr(1, 2)      # the third one has sx-ed qubit 1 first: it stays
+    s3 = plan(c3)[0]
+    assert re.search(r"ecr 1, diagonal stages", s3), s3
     # nothing is dropped once the control has seen a non-diagonal gate
     c2 = QuantumCircuit(3)
     c2.h(0); c2.cx(0, 1); c2.sx(2); c2.cx(2, 1); c2.cz(0, 2)
