@@ -158,8 +158,8 @@ extern "C" int qk_circuit_create(int n_qubits, int n_params, const qk_op* ops, i
         if (!r) { delete c; return fail(QK_ERR_INVALID, "qk_circuit_create: out of memory"); }
         r->n_qubits = n_qubits;
         r->n_params = n_params;
-        r->prog = c->prog;
-        r->consts = c->consts;
+        r->prog.assign(prog, prog + n_instr);      // (the caller's tables: plan_circuit may have appended a constant program to c's)
+        r->consts.assign(consts, consts + n_consts);
         const int rc2 = plan_circuit(*r, ops, n_ops, expr_off, n_expr, false);
         if (rc2) { delete r; delete c; return rc2; }
         c->rdm_plan = r;

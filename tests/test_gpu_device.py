@@ -232,3 +232,29 @@ def test_rccl_smoke_world_size_one():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["backend"] == "nccl" and out["all_gather_in_place"] and out["p2p"] and out["all_reduce_max"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,N,seed", [(8, 16384 + 5, 101), (10, 4096 + 3, 100), (11, 2048 + 1, 103), (12, 1024 + 5, 102), (12, 7, 102)])
+def test_simulate_rdm1_hardware_native_genome(n, N, seed):
+    """The reduced density matrices of GA genomes of the hardware-native alphabet: their ecr gates on qubits that are still
+    basis states become single-qubit gates and a constant angle program of the planner's own (qk_circuit.cpp section 1),
+    and a circuit that simulates with 8 amplitudes per thread carries a second plan for the fused mode, made from the
+    caller's tables.  The library's route, simulate + rdm1 by hand and the oracle agree."""
+    import torch
+    from quake_amd import device as qdev, genetic
+    from tests._helpers import psi_from_compiled
+    hw = {"single_non_parametric": ["Id", "X", "SX"], "single_parametric": ["RZ", "RZ"], "two_non_parametric": ["ECR"], "two_parametric": []}
+    genes = genetic.initial_population(1, n, 8, hw, n, rng=np.random.default_rng(seed))[0]
+    fmap, cols = genetic.to_quantum(genes, hw, n, 8, n, physical_qubits=list(range(n)), verbose=False)
+    circ = qdev.DeviceCircuit(fmap)
+    X = np.ascontiguousarray(np.random.default_rng(seed + n).uniform(0.02, 0.98, size=(N, n))[:, cols])
+    Xd = torch.from_numpy(X).cuda()
+    got = qdev.simulate_rdm1(circ, Xd)
+    by_hand = qdev.rdm1(circ.simulate(Xd), n)
+    torch.cuda.synchronize()
+    assert float((got - by_hand).abs().max()) < 1e-13
+    rows = np.unique(np.concatenate([[0, 1, N - 1], np.random.default_rng(n).integers(0, N, 4)]))
+    r = O.rdm1(psi_from_compiled(fmap, X[rows]), n)
+    want = np.stack([r[..., 0, 0].real, r[..., 1, 1].real, r[..., 0, 1].real, r[..., 0, 1].imag], axis=-1)
+    assert np.abs(got[torch.from_numpy(rows).cuda()].cpu().numpy() - want).max() < 1e-13
