@@ -48,7 +48,31 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     auto bad_q = [&](int q) { return q < 0 || q >= n; };
 
     // ---- 1. classify + peephole ------------------------------------------
+    static const bool basis_pairs_off = [] { const char* e = std::getenv("QK_PLAN_BASIS_CONTROLS"); return e && std::atoi(e) == 0; }();
     std::vector<Item> items;
+    // cx, cz and ecr are their own inverses: two of them on the same qubits with nothing in between on either qubit (id
+    // gates aside) are dropped together -- a genome draws a qubit's partner from its neighbours, so such pairs are frequent.
+    // hist[q]: the live items that touched q, in order.
+    std::vector<char> dead;
+    std::vector<std::vector<int>> hist(n);
+    auto push = [&](const Item& it) {
+        const int idx = (int)items.size();
+        items.push_back(it);
+        dead.push_back(0);
+        hist[it.q0].push_back(idx);
+        if (it.q1 >= 0) hist[it.q1].push_back(idx);
+    };
+    auto cancels = [&](bool diag, int kind, int q0, int q1) {
+        if (basis_pairs_off || hist[q0].empty() || hist[q1].empty() || hist[q0].back() != hist[q1].back()) return false;
+        const int j = hist[q0].back();
+        const Item& p = items[(size_t)j];
+        const bool same = p.diag == diag && p.kind == kind && ((p.q0 == q0 && p.q1 == q1) || (diag && p.q0 == q1 && p.q1 == q0));
+        if (!same) return false;
+        dead[(size_t)j] = 1;
+        hist[q0].pop_back();
+        hist[q1].pop_back();
+        return true;
+    };
     // basis[q]: 0 / 1 while only id, x and diagonal gates have acted on q -- the qubit is still |0> or |1> up to a phase --
     // and -1 after anything else.  A cx whose control is still |0> is the identity and a cz with either qubit still |0> as
     // well; a cx whose control is |1> is an x on its target.  (GA genomes draw their gates at random: the first gate on a
@@ -85,10 +109,10 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         if (o.gate == QK_CZ && (basis[o.q0] == 0 || basis[o.q1] == 0)) continue;
         if (o.gate == QK_CX && basis[o.q0] == 1) { o.gate = QK_X; o.q0 = o.q1; o.q1 = -1; }
         if (o.gate == QK_ECR && basis[o.q0] >= 0) {
-            items.push_back({true, TM_RZ, 0, o.q0, -1, half_pi()});
-            items.push_back({false, ST_U1, QK_SX, o.q1, -1, -1});
-            if (basis[o.q0] == 1) items.push_back({false, ST_U1, QK_X, o.q1, -1, -1});
-            items.push_back({false, ST_U1, QK_X, o.q0, -1, -1});
+            push({true, TM_RZ, 0, o.q0, -1, half_pi()});
+            push({false, ST_U1, QK_SX, o.q1, -1, -1});
+            if (basis[o.q0] == 1) push({false, ST_U1, QK_X, o.q1, -1, -1});
+            push({false, ST_U1, QK_X, o.q0, -1, -1});
             basis[o.q0] = 1 - basis[o.q0];
             basis[o.q1] = -1;
             continue;
@@ -102,22 +126,28 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
             const qk_op& x2 = ops[i + 2];
             if (p.gate == QK_P && p.q0 == o.q1 && p.expr >= 0 && p.expr < n_expr && x2.gate == QK_CX &&
                 x2.q0 == o.q0 && x2.q1 == o.q1) {
-                items.push_back({true, TM_ZZP, 0, o.q0, o.q1, p.expr});
+                push({true, TM_ZZP, 0, o.q0, o.q1, p.expr});
                 i += 2;
                 continue;
             }
         }
         switch (o.gate) {
             case QK_H: case QK_X: case QK_SX: case QK_RX: case QK_RY:
-                items.push_back({false, ST_U1, o.gate, o.q0, -1, par ? o.expr : -1});
+                push({false, ST_U1, o.gate, o.q0, -1, par ? o.expr : -1});
                 break;
-            case QK_RZ: items.push_back({true, TM_RZ, 0, o.q0, -1, o.expr}); break;
-            case QK_P: items.push_back({true, TM_P, 0, o.q0, -1, o.expr}); break;
-            case QK_CZ: items.push_back({true, TM_CZ, 0, o.q0, o.q1, -1}); break;
-            case QK_CX: items.push_back({false, ST_CX, o.gate, o.q0, o.q1, -1}); break;
-            case QK_ECR: items.push_back({false, ST_ECR, o.gate, o.q0, o.q1, -1}); break;
+            case QK_RZ: push({true, TM_RZ, 0, o.q0, -1, o.expr}); break;
+            case QK_P: push({true, TM_P, 0, o.q0, -1, o.expr}); break;
+            case QK_CZ: if (!cancels(true, TM_CZ, o.q0, o.q1)) push({true, TM_CZ, 0, o.q0, o.q1, -1}); break;
+            case QK_CX: if (!cancels(false, ST_CX, o.q0, o.q1)) push({false, ST_CX, o.gate, o.q0, o.q1, -1}); break;
+            case QK_ECR: if (!cancels(false, ST_ECR, o.q0, o.q1)) push({false, ST_ECR, o.gate, o.q0, o.q1, -1}); break;
             default: break;
         }
+    }
+    {      // (without the cancelled pairs)
+        std::vector<Item> live;
+        for (size_t k = 0; k < items.size(); ++k)
+            if (!dead[k]) live.push_back(items[k]);
+        items.swap(live);
     }
     c.n_gates = (int)items.size();
     expr_off = eoff.data();      // (the caller's angle programs, and the constant above when an ecr needed it)

@@ -251,3 +251,30 @@ def test_controls_that_are_still_basis_states_cost_nothing():
     c2.h(0); c2.cx(0, 1); c2.sx(2); c2.cx(2, 1); c2.cz(0, 2)
     got2, s2 = counts(c2)
     assert got2["cx"] == 2 and got2["terms"] == 1, s2
+
+
+def test_adjacent_self_inverse_pairs_cancel():
+    """qk_circuit.cpp section 1: cx, cz and ecr are their own inverses -- two of them on the same qubits with nothing but id
+    gates in between on either qubit are dropped together; a gate on one of the qubits in between keeps both."""
+    from quake_amd.circuit import QuantumCircuit
+
+    def two_qubit_counts(c):
+        s = plan(c)[0]
+        m = re.search(r"cx (\d+), ecr (\d+), diagonal stages (\d+) with (\d+) terms", s)
+        return (int(m.group(1)), int(m.group(2)), int(m.group(4))), s
+
+    def opened(n=3):      # every qubit has seen a non-diagonal gate: no basis-state shortcuts
+        c = QuantumCircuit(n)
+        for q in range(n):
+            c.sx(q)
+        return c
+
+    c = opened(); c.cx(0, 1); c.id(0); c.cx(0, 1); c.ecr(1, 2); c.ecr(1, 2); c.cz(0, 2); c.id(2); c.cz(2, 0)
+    got, s = two_qubit_counts(c)
+    assert got == (0, 0, 0), s
+    c = opened(); c.cx(0, 1); c.x(1); c.cx(0, 1); c.ecr(1, 2); c.ecr(2, 1); c.cz(0, 2); c.sx(0); c.cz(0, 2); c.cx(0, 1); c.cx(1, 0)
+    got, s = two_qubit_counts(c)
+    assert got == (4, 2, 2), s
+    c = opened(); c.cx(0, 1); c.cx(0, 1); c.cx(0, 1)      # three in a row: one is left
+    got, s = two_qubit_counts(c)
+    assert got == (1, 0, 0), s
