@@ -419,22 +419,55 @@ class QuantumCircuit:
 
         Data column k feeds the k-th parameter of the sorted ``parameters`` list.
         """
-        params = self.parameters
-        column_of = {p: k for k, p in enumerate(params)}
+        # one walk per angle expression: its postfix program (parameters as themselves, numbered once all are known), the
+        # constants interned by their bits, and the deepest the evaluator's stack gets
         consts: list = []
         const_index: dict = {}
+        seen: dict = {}
         ops, prog, off = [], [], [0]
+        unary, binary, pack = ParameterExpression._UNARY, ParameterExpression._BINARY, struct.pack
         for ins in self.data:
             expr = -1
             if ins.angle is not None:
-                if ins.angle.stack_depth() > MAX_EXPR_STACK:
+                depth = deepest = 0
+                todo = [(ins.angle, False)]
+                while todo:
+                    e, done = todo.pop()
+                    op = e.op
+                    if op == "const":
+                        key = pack("<d", e.args[0])
+                        i = const_index.get(key)
+                        if i is None:
+                            i = const_index[key] = len(consts)
+                            consts.append(e.args[0])
+                        prog.append((EX_CONST, i))
+                        depth += 1
+                        if depth > deepest: deepest = depth
+                    elif op == "param":
+                        seen[e] = True
+                        prog.append((EX_PARAM, e))
+                        depth += 1
+                        if depth > deepest: deepest = depth
+                    elif done:
+                        if len(e.args) == 1:
+                            prog.append((unary[op], 0))
+                        else:
+                            prog.append((binary[op], 0))
+                            depth -= 1
+                    else:
+                        todo.append((e, True))
+                        for arg in reversed(e.args):
+                            todo.append((arg, False))
+                if deepest > MAX_EXPR_STACK:
                     raise ValueError("gate-angle expression is nested too deeply for the device evaluator")
-                ins.angle.postfix(column_of, consts, const_index, prog)
                 off.append(len(prog))
                 expr = len(off) - 2
             q0 = ins.qubits[0]
             q1 = ins.qubits[1] if len(ins.qubits) > 1 else -1
             ops.append((GATE_CODES[ins.name], q0, q1, expr))
+        params = sorted(seen, key=Parameter.sort_key)
+        column_of = {p: k for k, p in enumerate(params)}
+        prog = [(o, column_of[x]) if o == EX_PARAM else (o, x) for o, x in prog]
         return CompiledCircuit(
             n_qubits=self.num_qubits,
             n_params=len(params),
