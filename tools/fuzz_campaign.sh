@@ -3,7 +3,7 @@
 set -o pipefail
 O=gpurun_out/fuzz_campaign.log
 : > $O
-run() { echo "== $*" >> $O; env "$@" timeout -k 10 400 python -u tools/fuzz_gpu.py --circuits 400 --grams ${GRAMS:-0} --seed $SEED 2>&1 | grep -v amdgpu.ids | tail -3 >> $O || exit 1; }
+run() { echo "== $*" >> $O; env "$@" timeout -k 10 400 python -u tools/fuzz_gpu.py --circuits 400 --grams ${GRAMS:-0} --seed $((SEED + ${SEED_OFFSET:-0})) 2>&1 | grep -v amdgpu.ids | tail -3 >> $O || exit 1; }
 if [ -z "$FUZZ_SECOND_HALF" ]; then
 SEED=101 GRAMS=200 run QK_NOOP=1
 SEED=102 run QK_SIM_PATH=reg
