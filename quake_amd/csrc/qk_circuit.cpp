@@ -62,15 +62,29 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         hist[it.q0].push_back(idx);
         if (it.q1 >= 0) hist[it.q1].push_back(idx);
     };
+    // (... and gates that commute with the pair may stand between its halves: diagonal gates on the control of a cx and on
+    // either qubit of a cz, x / sx / rx on the target of a cx and on the second qubit of an ecr)
     auto cancels = [&](bool diag, int kind, int q0, int q1) {
-        if (basis_pairs_off || hist[q0].empty() || hist[q1].empty() || hist[q0].back() != hist[q1].back()) return false;
-        const int j = hist[q0].back();
+        if (basis_pairs_off) return false;
+        auto commutes = [&](const Item& it, bool first) {
+            if (it.q1 >= 0) return false;
+            if (it.diag) return diag || (kind == ST_CX && first);
+            return !diag && !first && it.kind == ST_U1 && (it.gate == QK_X || it.gate == QK_SX || it.gate == QK_RX);
+        };
+        auto last_blocking = [&](int q, bool first) {
+            int k = (int)hist[q].size() - 1;
+            while (k >= 0 && commutes(items[(size_t)hist[q][(size_t)k]], first)) --k;
+            return k;
+        };
+        const int k0 = last_blocking(q0, true), k1 = last_blocking(q1, false);
+        if (k0 < 0 || k1 < 0 || hist[q0][(size_t)k0] != hist[q1][(size_t)k1]) return false;
+        const int j = hist[q0][(size_t)k0];
         const Item& p = items[(size_t)j];
         const bool same = p.diag == diag && p.kind == kind && ((p.q0 == q0 && p.q1 == q1) || (diag && p.q0 == q1 && p.q1 == q0));
         if (!same) return false;
         dead[(size_t)j] = 1;
-        hist[q0].pop_back();
-        hist[q1].pop_back();
+        hist[q0].erase(hist[q0].begin() + k0);
+        hist[q1].erase(hist[q1].begin() + k1);
         return true;
     };
     // basis[q]: 0 / 1 while only id, x and diagonal gates have acted on q -- the qubit is still |0> or |1> up to a phase --
