@@ -167,6 +167,9 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     expr_off = eoff.data();      // (the caller's angle programs, and the constant above when an ecr needed it)
     n_expr = (int)eoff.size() - 1;
 
+    bool two_qubit_diag = false;      // cz or cx p cx anywhere in the circuit
+    for (const Item& it : items) two_qubit_diag = two_qubit_diag || (it.diag && it.q1 >= 0);
+
     // ---- 1b. runs of single-qubit gates on one qubit -> one composite matrix -------------------
     // chain[q]: the single-qubit items on q since the last two-qubit item that touched q.  Gates on
     // different qubits commute, so a chain may be emitted as a block right before the next two-qubit
@@ -184,8 +187,6 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
         // chain is the first thing on its qubit and starts with a Hadamard (h p: the Hadamards are the constant product
         // state, the phases one diagonal stage: the Z map), and not in circuits with cz / zz terms, whose stages exist anyway.
         static const bool env_off = [] { const char* e = std::getenv("QK_PLAN_RZ_CHAINS"); return e && std::atoi(e) == 0; }();
-        bool two_qubit_diag = false;
-        for (const Item& it : items) two_qubit_diag = two_qubit_diag || (it.diag && it.q1 >= 0);
         const bool rz_chains = !two_qubit_diag && !env_off;
         std::vector<std::vector<Item>> chain(n);
         std::vector<Item> out;
@@ -1219,6 +1220,10 @@ int plan_circuit(qk_circuit& c, const qk_op* ops, int n_ops, const int32_t* expr
     // workgroups (QK_REG_QTAB=0 / 1: A/B runs)
     auto plan_q = [&](const int Lv, const size_t lds_limit, size_t* dry_lds = nullptr) -> bool {
         static const int q_env = std::getenv("QK_REG_QTAB") ? std::atoi(std::getenv("QK_REG_QTAB")) : -1;
+        if (!two_qubit_diag) {      // (no term between two qubits: nothing a ratio table could take, one draft is enough)
+            q_tables = false;
+            return plan_reg(Lv, lds_limit, dry_lds);
+        }
         size_t l1 = 0, l0 = 0;
         q_tables = true;
         const bool ok1 = q_env != 0 && plan_reg(Lv, lds_limit, &l1);
