@@ -95,6 +95,9 @@ int qk_block_to_host_async(const double* K_dev, int64_t ldk, int64_t rows, int64
  * column `arg` of QK_EX_PARAM directly, so the sorted-parameter binding is resolved
  * by the caller when it numbers the columns.
  *   expr_off has n_expr + 1 entries; program e is prog[expr_off[e] .. expr_off[e+1]).
+ * The planner rewrites the gate list by exact identities only (runs of single-qubit gates multiplied into one
+ * matrix, cx / cz / ecr on qubits that are still basis states, self-inverse pairs: DESIGN.md 4.2p); what the
+ * simulators return equals the gate-by-gate product up to rounding (1e-12 in the parity tests, 1e-15 typical).
  */
 int qk_circuit_create(int n_qubits, int n_params,
                       const qk_op* ops, int n_ops,
